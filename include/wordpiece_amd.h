@@ -1,0 +1,112 @@
+/*
+ * wordpiece_amd.h — C ABI of the MI355X-native Linear WordPiece encoder.
+ *
+ * This is the drop-in boundary for the reference's Linear path
+ * (gleb-kov/wordpiece, src/word_piece.hpp:12-19 → src/linear.cpp:321-374).  The
+ * reference has no FFI of its own: its boundary is the C++ header
+ * word_piece.hpp, re-implemented on top of this ABI in include/word_piece.hpp.
+ * Every entry point below cites the reference interface it replaces.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function
+ * returns WP_OK (0) or a WP_ERR_* code and wp_last_error() then holds the
+ * message for the calling thread.  A vocab handle is single-caller (the
+ * reference is effectively single-caller too: its global thread pool barrier
+ * waits on all tasks, utils.cpp:25-28).  The library needs a HIP device: there
+ * is NO CPU fallback — without a GPU every compute entry point fails loudly
+ * with WP_ERR_NO_DEVICE.
+ */
+#ifndef WORDPIECE_AMD_H
+#define WORDPIECE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WP_OK 0
+#define WP_ERR_EMPTY_WORD 1 /* "Vocab word is empty"   utils.cpp:99-101  */
+#define WP_ERR_TOO_LARGE 2  /* "64bit not implemented" linear.cpp:104-106 */
+#define WP_ERR_HIP 3        /* HIP runtime error (replaces "SACA return code: N", linear.cpp:139-141) */
+#define WP_ERR_NO_DEVICE 4
+#define WP_ERR_IO 5  /* file could not be opened / mapped (Boost throws there) */
+#define WP_ERR_ARG 6
+
+typedef struct wp_vocab wp_vocab;
+
+/* ---- vocabulary: utils.cpp:81-137 (WordPieceToken, parseVocab, readVocabFromFile) ----
+ * Lines are raw UTF-8 without terminators; `##` prefix, [special] and malformed
+ * classification exactly as the reference.  The handle also caches the device
+ * copy of the vocab symbol stream (a pure function of the vocab). */
+int wp_vocab_create(const char *const *lines, const size_t *line_bytes, size_t n_lines,
+                    wp_vocab **out);
+/* same, lines given as one buffer + n_lines+1 offsets (ctypes/JNI friendly) */
+int wp_vocab_create_packed(const char *buf, const int64_t *offsets, int64_t n_lines,
+                           wp_vocab **out);
+/* utils.cpp:123-137: std::getline semantics (LF only; a CR stays in the token) */
+int wp_vocab_from_file(const char *vocab_file, wp_vocab **out);
+void wp_vocab_destroy(wp_vocab *v);
+int64_t wp_vocab_size(const wp_vocab *v);
+int32_t wp_vocab_unk_id(const wp_vocab *v);              /* utils.hpp:30-33, -1 if absent */
+int32_t wp_vocab_token_flags(const wp_vocab *v, int64_t i); /* bit0 prefix, bit1 special, bit2 malformed */
+int64_t wp_vocab_token_len(const wp_vocab *v, int64_t i);
+
+/* ---- the hot path: linear.cpp:321-328 encodeLinearWordPiece ----
+ * replaces word_piece::linear::encode(text, vocab)        word_piece.hpp:12, linear.cpp:332-335
+ * host UTF-8 in, malloc'd int32 ids out (free with wp_free). */
+int wp_linear_encode(wp_vocab *v, const char *utf8, size_t nbytes, int32_t **ids, size_t *n_ids);
+
+/* Same path with the text already resident in device memory and the ids left
+ * there (what bench.py times; what a training input pipeline would consume).
+ * `d_ids` is owned by the handle and valid until the next call on it. */
+int wp_linear_encode_device(wp_vocab *v, const void *d_utf8, size_t nbytes,
+                            const int32_t **d_ids, size_t *n_ids);
+
+/* replaces word_piece::linear::encode(text_file, vocab_file)   word_piece.hpp:14, linear.cpp:337-341 */
+int wp_linear_encode_file(const char *text_file, const char *vocab_file, int32_t **ids,
+                          size_t *n_ids);
+/* replaces word_piece::linear::encodeExternal(...)              word_piece.hpp:16-19, linear.cpp:343-374
+ * batches of memory_limit/20 bytes extended to the next space; ids appended to
+ * out_file as decimal text, each followed by one ' ' (utils.cpp:30-35). */
+int wp_linear_encode_external(const char *text_file, const char *vocab_file, const char *out_file,
+                              size_t memory_limit);
+
+/* ---- options ---- */
+#define WP_OPT_FULL_DEPTH 1   /* 1: sort suffixes to full depth (true suffix array).  0 (default):
+                                 stop prefix doubling once the sorted depth exceeds the longest
+                                 vocab token — token ids are identical for duplicate-free vocabs;
+                                 vocabs with duplicate lines force full depth automatically. */
+#define WP_OPT_DEVICE 2       /* HIP device ordinal used by this handle (default: current) */
+#define WP_OPT_KEEP_DEBUG 3   /* 1: keep SA/rank/LCP/best arrays for wp_linear_debug_fetch */
+#define WP_OPT_STAGE_TIMING 4 /* 1: record per-stage device times with HIP events */
+#define WP_OPT_LCP_KASAI 5    /* 1: build LCP with the chunked Kasai kernel (linear.cpp:18-70)
+                                 instead of deriving it inside the doubling rounds */
+int wp_set_option(wp_vocab *v, int option, int64_t value);
+
+/* ---- statistics of the last encode on this handle (for bench.py / roofline) ---- */
+typedef struct {
+  int64_t n_bytes, n_text, n_total, alphabet, longest_token, n_ids;
+  int32_t symbol_bits, symbols_per_key, rounds, sorted_depth, full_depth;
+  int64_t radix_pass_elems;   /* sum over all radix passes of the elements moved      */
+  int32_t radix_passes;       /* number of radix scatter launches                      */
+  int64_t active_per_round[40];
+  double ms_total, ms_decode, ms_sa, ms_lcp, ms_scan, ms_walk; /* WP_OPT_STAGE_TIMING */
+  double ms_radix_scatter;    /* device time inside radix scatter kernels (HIP events) */
+} wp_stats;
+int wp_get_stats(const wp_vocab *v, wp_stats *out);
+
+/* ---- debug fetch (WP_OPT_KEEP_DEBUG): copies device intermediates to host ----
+ * which: 0 S (dense symbols as int32, n), 1 SA (n), 2 rank (n), 3 lcp (n-1; -1 = "at least
+ * sorted_depth"), 4 best_prefix (n), 5 best_suffix (n), 6 code points (n_text) */
+int wp_linear_debug_fetch(const wp_vocab *v, int which, int32_t *out, size_t capacity,
+                          size_t *n_out);
+
+void wp_free(void *p);
+const char *wp_last_error(void);
+int wp_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

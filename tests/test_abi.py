@@ -1,0 +1,73 @@
+"""CPU checks of the host side: the C-ABI library loads and exports every symbol the header
+declares, the host vocab logic matches the oracle, and compute entry points fail loudly
+without a GPU (no fallback)."""
+import os
+import re
+
+import pytest
+
+import oracle_lib as O
+import wordpiece_amd as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not os.path.exists(W.LIB_PATH):
+        from wordpiece_amd import build
+        build.build()
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "wordpiece_amd.h")).read()
+    declared = set(re.findall(r"\b(wp_[a-z_]+)\s*\(", hdr))
+    assert declared == set(W.ABI_SYMBOLS)
+    L = W.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_vocab_classification_matches_oracle():
+    words = ["a", "##a", "[UNK]", "[a]", "##[a]", "...", ".", "##..", "a.", "[]", "#", "###", "####", "[ ]", ", ",
+             "aé中", "##中", "a b", "[CLS", "CLS]", b"\xffa", b"##\xffb"]
+    gv, ov = W.Vocab(words), O.Vocab(words)
+    assert len(gv) == ov.size and gv.unk_id == ov.unk_id == 2
+    for i in range(len(words)):
+        assert gv.token_flags(i) == ov.flags(i), words[i]
+        assert gv.token_len(i) == len(ov.word(i)), words[i]
+
+
+def test_empty_word_error_message():
+    for bad in (["a", "##"], ["a", ""], [b"\xff"]):
+        with pytest.raises(W.WordPieceError, match="Vocab word is empty"):
+            W.Vocab(bad)
+
+
+def test_vocab_from_file_getline_semantics(tmp_path):
+    p = tmp_path / "vocab.txt"
+    p.write_bytes(b"[UNK]\na\r\n##b\nlast")
+    v = W.Vocab(file=str(p))
+    assert len(v) == 4 and v.unk_id == 0
+    assert v.token_len(1) == 2  # the CR stays in the token (utils.cpp:123-137)
+
+
+def test_empty_text_needs_no_device():
+    assert W.linear.encode("", ["a"]) == []
+
+
+def test_no_cpu_fallback():
+    if W.lib().wp_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(W.WordPieceError, match="no HIP device"):
+        W.linear.encode("ab", ["a", "##b"])
+
+
+def test_shard_bounds_cut_at_whitespace():
+    data = b"alpha beta\tgamma\ndelta epsilon zeta"
+    for ws in (1, 2, 3, 4, 8):
+        b = W.shard_bounds(data, ws)
+        assert b[0][0] == 0 and b[-1][1] == len(data)
+        for (s0, e0), (s1, e1) in zip(b, b[1:]):
+            assert e0 == s1
+            assert e0 == len(data) or data[e0] in b" \t\n"

@@ -1,0 +1,191 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle.
+
+Every stage is diffed in full-depth mode (SA, rank and LCP are then unique and must be
+bit-identical to the oracle's); the default depth-capped mode must give identical ids."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import wordpiece_amd as W
+from wordpiece_amd import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name):
+    with open(os.path.join(HERE, "golden", name)) as f:
+        return json.load(f)["cases"]
+
+
+def _combine(d, vocab_lens, which):
+    """The reference's merge of the left and right scan answers (linear.cpp:234-250) per SA slot."""
+    n = d["n"]
+    left = d["best_left_" + which]
+    right = d["best_right_" + which][::-1]  # right arrays are in scan order: result[i] <-> slot n-1-i
+    lens = np.asarray(list(vocab_lens) + [0], dtype=np.int64)
+    lx, ly = lens[left], lens[right]
+    both = (left != -1) & (right != -1)
+    out = np.where(both, np.where(lx > ly, left, right), np.maximum(left, right))
+    assert len(out) == n
+    return out.astype(np.int32)
+
+
+def check_all_stages(text, vocab, label=""):
+    text = text if isinstance(text, bytes) else text.encode("utf8")
+    ov = O.Vocab(vocab)
+    d = ov.encode_debug(text)
+    gv = W.Vocab(vocab)
+    gv.set_option(W.WP_OPT_FULL_DEPTH, 1)
+    ids = gv.encode(text)
+    n = d["n"]
+    if len(text) and d["n_text"] > 0:
+        cps = gv.debug_fetch(6, d["n_text"])
+        assert np.array_equal(cps, d["S"][:d["n_text"]]), label + " code points"
+        sym = gv.debug_fetch(0, n)
+        uniq = np.unique(d["S"])
+        assert np.array_equal(sym, np.searchsorted(uniq, d["S"]) + 1), label + " dense symbols"
+        assert np.array_equal(gv.debug_fetch(1, n), d["SA"]), label + " suffix array"
+        assert np.array_equal(gv.debug_fetch(2, n), d["rank"]), label + " rank"
+        assert np.array_equal(gv.debug_fetch(3, n), d["lcp"]), label + " lcp"
+        lens = [ov_len for ov_len in (O.lib().wpo_vocab_token_len(ov._h, i) for i in range(ov.size))]
+        assert np.array_equal(gv.debug_fetch(4, n), _combine(d, lens, "prefix")), label + " best prefix"
+        assert np.array_equal(gv.debug_fetch(5, n), _combine(d, lens, "suffix")), label + " best suffix"
+    assert np.array_equal(ids, d["ids"]), label + " ids (full depth)"
+    gv2 = W.Vocab(vocab)
+    assert np.array_equal(gv2.encode(text), d["ids"]), label + " ids (depth capped)"
+    return gv2.stats()
+
+
+@pytest.mark.parametrize("case", _load("reference_tests_cpp.json"))
+def test_reference_tests_cpp_vectors(case):
+    text = bytes.fromhex(case["text_hex"])
+    vocab = [bytes.fromhex(w) for w in case["vocab_hex"]]
+    if case["expected"] is not None:
+        assert W.Vocab(vocab).encode(text).tolist() == case["expected"]
+    check_all_stages(text, vocab)
+
+
+@pytest.mark.parametrize("case", _load("survey_probed_cases.json"), ids=lambda c: c["name"])
+def test_survey_probed_cases(case):
+    text = bytes.fromhex(case["text_hex"])
+    vocab = [bytes.fromhex(w) for w in case["vocab_hex"]]
+    assert W.Vocab(vocab).encode(text).tolist() == case["expected"]
+    check_all_stages(text, vocab)
+
+
+def test_errors_match_reference():
+    with pytest.raises(W.WordPieceError, match="Vocab word is empty"):
+        W.Vocab(["a", "##"])
+    assert W.linear.encode("", ["a"]) == []
+
+
+def test_random_small_adversarial():
+    rng = random.Random(4321)
+    alpha = "ab-, .c"
+    done = 0
+    while done < 300:
+        nt = rng.randint(1, 8)
+        vocab = set()
+        while len(vocab) < nt:
+            w = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 4)))
+            if rng.random() < 0.4:
+                w = "##" + w
+            vocab.add(w)
+        vocab = sorted(vocab)
+        rng.shuffle(vocab)
+        text = "".join(rng.choice(alpha) for _ in range(rng.randint(0, 40)))
+        try:
+            O.Vocab(vocab)
+        except O.OracleError:
+            continue
+        check_all_stages(text, vocab, label=repr((text, vocab)))
+        done += 1
+
+
+def test_random_split_grid():
+    """tests.cpp:219-246 testRandomSplit (own generator): positive and negative vocabularies."""
+    k = 0
+    for text_len in (10, 35, 100, 300, 1000, 5000):
+        for parts in (2, 7, 30, 100):
+            for positive in (True, False):
+                s, vocab = synth.random_split_case(1000 + k, text_len, parts, positive)
+                k += 1
+                if vocab:
+                    check_all_stages(s, vocab, label="split %d/%d" % (text_len, parts))
+
+
+def test_invalid_utf8_and_multibyte():
+    rng = random.Random(7)
+    pool = [b"a", b"b", b" ", b"\xd0\xbf", b"\xe4\xb8\xad", b"\xf0\x9f\x98\x80", b"\xff", b"\xc0\x80", b"\xed\xa0\x80",
+            b"\xe2\x96", b"\x80", b"\xe2\x96\x81", b"\xc3", b"\xf0\x9f", b",", b"\xe6\x96\x87"]
+    vocab = ["a", "b", "##a", "##b", "п", "##п", "中", "文", "ab", "##ab", ",", "😀", "[UNK]"]
+    for _ in range(60):
+        text = b"".join(rng.choice(pool) for _ in range(rng.randint(1, 200)))
+        check_all_stages(text, vocab, label=repr(text))
+
+
+def test_english_1mb_all_stages():
+    text, vocab = synth.english_corpus(1_000_000, seed=3, vocab_size=5000)
+    st = check_all_stages(text, vocab, "english 1MB")
+    assert st["n_ids"] > 100000
+
+
+def test_multilingual_all_stages():
+    text, vocab = synth.multilingual_corpus(600_000, seed=5, vocab_size=20000)
+    check_all_stages(text, vocab, "multilingual")
+
+
+def test_deep_prefix_all_stages():
+    text, vocab = synth.deep_prefix_corpus(300_000, seed=9, word_len=128, n_stems=16, suffix_stems=4, suffix_len=32)
+    check_all_stages(text, vocab, "deep prefixes")
+
+
+def test_duplicate_vocab_lines_force_full_depth():
+    v = W.Vocab(["ab", "x", "ab"])
+    assert v.encode("ab ab").tolist() == [0, 0]
+    assert v.stats()["full_depth"] == 1
+
+
+def test_kasai_kernel_gives_same_lcp():
+    text, vocab = synth.english_corpus(300_000, seed=8, vocab_size=3000)
+    d = O.Vocab(vocab).encode_debug(text)
+    gv = W.Vocab(vocab)
+    gv.set_option(W.WP_OPT_LCP_KASAI, 1)
+    ids = gv.encode(text)
+    assert np.array_equal(gv.debug_fetch(3, d["n"]), d["lcp"])
+    assert np.array_equal(ids, d["ids"])
+
+
+def test_english_16mb_ids_and_properties():
+    """BASELINE-size properties: ids equal the oracle's, and the depth-capped SA is a permutation
+    sorted by the first sorted_depth symbols."""
+    text, vocab = synth.english_corpus(16_000_000, seed=21)
+    O.use_libsais(True)
+    try:
+        exp = O.Vocab(vocab).encode(text, threads=8)
+    finally:
+        O.use_libsais(False)
+    gv = W.Vocab(vocab)
+    ids = gv.encode(text)
+    assert np.array_equal(ids, exp)
+    st = gv.stats()
+    n = st["n_total"]
+    sa = gv.debug_fetch(1, n).astype(np.int64)
+    assert np.array_equal(np.sort(sa), np.arange(n))
+    sym = gv.debug_fetch(0, n).astype(np.int64)
+    depth = min(st["sorted_depth"], 64)
+    pad = np.concatenate([sym, np.zeros(depth, dtype=np.int64)])
+    idx = np.random.default_rng(0).integers(0, n - 1, 200000)
+    a, b = sa[idx], sa[idx + 1]
+    for k in range(depth):  # lexicographic compare of the first `depth` symbols, sampled
+        ca, cb = pad[a + k], pad[b + k]
+        assert np.all(ca <= cb)
+        keep = ca == cb
+        a, b = a[keep], b[keep]
+        if len(a) == 0:
+            break

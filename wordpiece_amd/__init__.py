@@ -1,0 +1,207 @@
+"""wordpiece_amd — MI355X-native Linear WordPiece (the src/linear.cpp path of gleb-kov/wordpiece).
+
+Host-side mirror of the reference's `word_piece::linear` API on top of the C ABI in
+include/wordpiece_amd.h (libwordpiece_amd.so, hand-written HIP for gfx950):
+
+    from wordpiece_amd import linear
+    ids = linear.encode("self-made", ["self", "made", "-", "##made"])     # word_piece.hpp:12
+    ids = linear.encode("text.txt", "vocab.txt")                           # word_piece.hpp:14
+    linear.encodeExternal("text.txt", "vocab.txt", "ids.txt", 500_000_000)  # word_piece.hpp:16
+
+There is no CPU fallback: without the built extension or without a GPU every call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwordpiece_amd.so")
+
+WP_OPT_FULL_DEPTH, WP_OPT_DEVICE, WP_OPT_KEEP_DEBUG, WP_OPT_STAGE_TIMING, WP_OPT_LCP_KASAI = 1, 2, 3, 4, 5
+
+# every symbol include/wordpiece_amd.h declares (checked by the CPU test-suite)
+ABI_SYMBOLS = [
+    "wp_vocab_create", "wp_vocab_create_packed", "wp_vocab_from_file", "wp_vocab_destroy", "wp_vocab_size",
+    "wp_vocab_unk_id", "wp_vocab_token_flags", "wp_vocab_token_len", "wp_linear_encode",
+    "wp_linear_encode_device", "wp_linear_encode_file", "wp_linear_encode_external", "wp_set_option",
+    "wp_get_stats", "wp_linear_debug_fetch", "wp_free", "wp_last_error", "wp_device_count",
+]
+
+
+class WordPieceError(RuntimeError):
+    """Mirrors the std::runtime_error the reference throws (message = wp_last_error())."""
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_bytes", C.c_int64), ("n_text", C.c_int64), ("n_total", C.c_int64), ("alphabet", C.c_int64),
+                ("longest_token", C.c_int64), ("n_ids", C.c_int64),
+                ("symbol_bits", C.c_int32), ("symbols_per_key", C.c_int32), ("rounds", C.c_int32),
+                ("sorted_depth", C.c_int32), ("full_depth", C.c_int32),
+                ("radix_pass_elems", C.c_int64), ("radix_passes", C.c_int32),
+                ("active_per_round", C.c_int64 * 40),
+                ("ms_total", C.c_double), ("ms_decode", C.c_double), ("ms_sa", C.c_double), ("ms_lcp", C.c_double),
+                ("ms_scan", C.c_double), ("ms_walk", C.c_double), ("ms_radix_scatter", C.c_double)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "active_per_round"}
+        d["active_per_round"] = [int(x) for x in self.active_per_round[:max(self.rounds, 0)]]
+        return d
+
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP extension; fails loudly if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WordPieceError("HIP extension missing: %s (run `python -m wordpiece_amd.build`)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i32p = C.c_void_p, C.POINTER(C.c_int32)
+        L.wp_vocab_create.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(vp)]
+        L.wp_vocab_create_packed.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.c_int64, C.POINTER(vp)]
+        L.wp_vocab_from_file.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.wp_vocab_destroy.argtypes = [vp]
+        L.wp_vocab_destroy.restype = None
+        L.wp_vocab_size.argtypes = [vp]
+        L.wp_vocab_size.restype = C.c_int64
+        L.wp_vocab_unk_id.argtypes = [vp]
+        L.wp_vocab_unk_id.restype = C.c_int32
+        L.wp_vocab_token_flags.argtypes = [vp, C.c_int64]
+        L.wp_vocab_token_flags.restype = C.c_int32
+        L.wp_vocab_token_len.argtypes = [vp, C.c_int64]
+        L.wp_vocab_token_len.restype = C.c_int64
+        L.wp_linear_encode.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32p), C.POINTER(C.c_size_t)]
+        L.wp_linear_encode_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.wp_linear_encode_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(i32p), C.POINTER(C.c_size_t)]
+        L.wp_linear_encode_external.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.wp_set_option.argtypes = [vp, C.c_int, C.c_int64]
+        L.wp_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.wp_linear_debug_fetch.argtypes = [vp, C.c_int, i32p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.wp_free.argtypes = [vp]
+        L.wp_free.restype = None
+        L.wp_last_error.restype = C.c_char_p
+        L.wp_device_count.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise WordPieceError(lib().wp_last_error().decode("utf8", "replace"))
+
+
+def _bytes(x):
+    return bytes(x) if isinstance(x, (bytes, bytearray, memoryview)) else x.encode("utf8")
+
+
+class Vocab:
+    """Opaque vocabulary handle (wp_vocab): parsed like utils.cpp:81-137, cached on the device."""
+
+    def __init__(self, lines=None, file=None, device=None):
+        self._h = C.c_void_p()
+        if file is not None:
+            _check(lib().wp_vocab_from_file(_bytes(file), C.byref(self._h)))
+        else:
+            ls = [_bytes(w) for w in lines]
+            off = np.zeros(len(ls) + 1, dtype=np.int64)
+            if ls:
+                off[1:] = np.cumsum([len(w) for w in ls])
+            _check(lib().wp_vocab_create_packed(b"".join(ls), off.ctypes.data_as(C.POINTER(C.c_int64)), len(ls),
+                                                C.byref(self._h)))
+        if device is not None:
+            self.set_option(WP_OPT_DEVICE, device)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.wp_vocab_destroy(self._h)
+            self._h = None
+
+    def __len__(self):
+        return lib().wp_vocab_size(self._h)
+
+    @property
+    def unk_id(self):
+        return lib().wp_vocab_unk_id(self._h)
+
+    def token_flags(self, i):
+        return lib().wp_vocab_token_flags(self._h, i)
+
+    def token_len(self, i):
+        return lib().wp_vocab_token_len(self._h, i)
+
+    def set_option(self, opt, value):
+        _check(lib().wp_set_option(self._h, opt, int(value)))
+
+    def stats(self):
+        s = Stats()
+        _check(lib().wp_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def encode(self, text):
+        """Host UTF-8 bytes/str -> numpy int32 ids (wp_linear_encode)."""
+        b = _bytes(text)
+        ids = C.POINTER(C.c_int32)()
+        n = C.c_size_t()
+        _check(lib().wp_linear_encode(self._h, b, len(b), C.byref(ids), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.int32)
+        out = np.ctypeslib.as_array(ids, shape=(n.value,)).copy()
+        lib().wp_free(ids)
+        return out
+
+    def encode_device(self, d_ptr, nbytes):
+        """Text already in HBM at `d_ptr` -> (device pointer of int32 ids, count).  The id buffer is
+        owned by the handle and valid until the next call."""
+        d_ids = C.c_void_p()
+        n = C.c_size_t()
+        _check(lib().wp_linear_encode_device(self._h, C.c_void_p(d_ptr), nbytes, C.byref(d_ids), C.byref(n)))
+        return d_ids.value, n.value
+
+    def debug_fetch(self, which, capacity):
+        out = np.zeros(max(capacity, 1), dtype=np.int32)
+        n = C.c_size_t()
+        _check(lib().wp_linear_debug_fetch(self._h, which, out.ctypes.data_as(C.POINTER(C.c_int32)), capacity,
+                                           C.byref(n)))
+        return out[:n.value]
+
+
+class _Linear:
+    """word_piece::linear of the reference (src/word_piece.hpp:10-21)."""
+
+    @staticmethod
+    def encode(text, vocab):
+        if isinstance(vocab, (str, bytes)):  # (text_file, vocab_file) overload, linear.cpp:337-341
+            ids = C.POINTER(C.c_int32)()
+            n = C.c_size_t()
+            _check(lib().wp_linear_encode_file(_bytes(text), _bytes(vocab), C.byref(ids), C.byref(n)))
+            out = np.ctypeslib.as_array(ids, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int32)
+            if n.value:
+                lib().wp_free(ids)
+            return out.tolist()
+        return Vocab(vocab).encode(text).tolist()  # linear.cpp:332-335
+
+    @staticmethod
+    def encodeExternal(text_file, vocab_file, out_file, memory_limit):  # linear.cpp:343-374
+        _check(lib().wp_linear_encode_external(_bytes(text_file), _bytes(vocab_file), _bytes(out_file),
+                                               int(memory_limit)))
+
+
+linear = _Linear()
+
+
+def shard_bounds(data, world_size):
+    """Cuts `data` (bytes) into world_size byte ranges at ASCII whitespace: each cut
+    is advanced to the next whitespace byte so no word straddles two shards."""
+    n = len(data)
+    mv = memoryview(data)
+    cuts = [0]
+    for r in range(1, world_size):
+        p = max(cuts[-1], n * r // world_size)
+        while p < n and mv[p] not in (9, 10, 11, 12, 13, 32):
+            p += 1
+        cuts.append(p)
+    cuts.append(n)
+    return [(cuts[i], cuts[i + 1]) for i in range(world_size)]

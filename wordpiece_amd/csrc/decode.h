@@ -1,0 +1,177 @@
+// decode.h — UTF-8 decode, character classes, alphabet compaction and the S = text·1·vocab build.
+//
+// Replaces utils::parseText / vkcom::decode_utf8 (utils.cpp:37-79, utf8.cpp:54-90,130-147) and the
+// S build of linear.cpp:77-103.  Decoding is data-parallel: a continuation byte never yields a code
+// point (it is consumed by a valid lead byte or dropped as invalid), and a non-continuation byte
+// is always a decode point (a valid sequence only ever swallows continuation bytes), so every
+// byte is classified independently and valid leads are stream-compacted.
+#pragma once
+#include "primitives.h"
+
+namespace wp {
+
+constexpr int kDecBytes = 16;
+constexpr int kDecTile = kBlock * kDecBytes;  // 4096 input bytes per workgroup
+constexpr uint32_t kCpTableSize = 0x110000;   // used[] / lut[] cover every code point
+
+// loads this thread's 16 bytes + 4 halo bytes into b[20] (zero padded past nbytes)
+__device__ __forceinline__ void load_bytes20(const uint8_t *__restrict__ text, size_t nbytes, size_t off,
+                                             uint8_t (&b)[20]) {
+  uint32_t w[5];
+  const size_t nwords = (nbytes + 3) / 4;  // the buffer is allocated padded to 16 bytes
+  const uint32_t *t32 = reinterpret_cast<const uint32_t *>(text);
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    size_t wi = off / 4 + k;
+    w[k] = wi < nwords ? t32[wi] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < 20; k++) {
+    uint32_t v = (w[k / 4] >> (8 * (k % 4))) & 0xffu;
+    b[k] = (off + k < nbytes) ? static_cast<uint8_t>(v) : 0;
+  }
+}
+
+// pass 1: number of valid code points per tile, and the number of input bytes they consume
+// (consumed != nbytes  <=>  the reference would print its invalid-unicode warning, utf8.cpp:143-145)
+__global__ __launch_bounds__(kBlock) void decode_count_kernel(const uint8_t *__restrict__ text, size_t nbytes,
+                                                              uint32_t *__restrict__ tile_counts,
+                                                              unsigned long long *__restrict__ consumed) {
+  __shared__ uint32_t sm[8];
+  const size_t off = static_cast<size_t>(blockIdx.x) * kDecTile + static_cast<size_t>(threadIdx.x) * kDecBytes;
+  uint32_t cnt = 0, used_bytes = 0;
+  if (off < nbytes) {
+    uint8_t b[20];
+    load_bytes20(text, nbytes, off, b);
+#pragma unroll
+    for (int j = 0; j < kDecBytes; j++) {
+      if (off + j < nbytes) {
+        if ((b[j] & 0xc0u) != 0x80u) {
+          uint32_t cp = decode_one(&b[j], static_cast<int64_t>(nbytes - (off + j)));
+          if (cp != kInvalidUnicode) {
+            cnt++;
+            used_bytes += cp < 0x80 ? 1 : cp < 0x800 ? 2 : cp < 0x10000 ? 3 : 4;
+          }
+        }
+      }
+    }
+  }
+  uint32_t tot, tot_bytes;
+  (void)block_excl_sum(cnt, sm, tot);
+  (void)block_excl_sum(used_bytes, sm, tot_bytes);
+  if (threadIdx.x == 0) {
+    tile_counts[blockIdx.x] = tot;
+    atomicAdd(consumed, static_cast<unsigned long long>(tot_bytes));
+  }
+}
+
+// pass 2: write code points, class bytes and mark used code points
+__global__ __launch_bounds__(kBlock) void decode_write_kernel(
+    const uint8_t *__restrict__ text, size_t nbytes, const uint32_t *__restrict__ tile_prefix,
+    uint32_t *__restrict__ cps, uint8_t *__restrict__ cls, uint32_t *__restrict__ used,
+    const uint32_t *__restrict__ soft, int nsoft) {
+  __shared__ uint32_t sm[8];
+  __shared__ uint32_t scp[kDecTile];
+  __shared__ uint32_t low_used[8];  // bitmap of code points < 256 seen by this tile
+  if (threadIdx.x < 8) low_used[threadIdx.x] = 0;
+  const size_t off = static_cast<size_t>(blockIdx.x) * kDecTile + static_cast<size_t>(threadIdx.x) * kDecBytes;
+  uint32_t cp[kDecBytes];
+  uint32_t cnt = 0;
+  if (off < nbytes) {
+    uint8_t b[20];
+    load_bytes20(text, nbytes, off, b);
+#pragma unroll
+    for (int j = 0; j < kDecBytes; j++) {
+      cp[j] = kInvalidUnicode;
+      if (off + j < nbytes && (b[j] & 0xc0u) != 0x80u) {
+        cp[j] = decode_one(&b[j], static_cast<int64_t>(nbytes - (off + j)));
+        if (cp[j] != kInvalidUnicode) cnt++;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kDecBytes; j++) cp[j] = kInvalidUnicode;
+  }
+  uint32_t tot;
+  uint32_t pos = block_excl_sum(cnt, sm, tot);
+#pragma unroll
+  for (int j = 0; j < kDecBytes; j++) {
+    if (cp[j] != kInvalidUnicode) {
+      scp[pos++] = cp[j];
+      if (cp[j] < 256) {
+        atomicOr(&low_used[cp[j] >> 5], 1u << (cp[j] & 31));
+      } else {
+        used[cp[j]] = 1u;
+      }
+    }
+  }
+  __syncthreads();
+  const size_t out_base = tile_prefix[blockIdx.x];
+  for (uint32_t k = threadIdx.x; k < tot; k += kBlock) {
+    const uint32_t c = scp[k];
+    cps[out_base + k] = c;
+    uint8_t f = 0;
+    if (is_space(c)) f |= kClsSpace;
+    if (is_spacing_char(c)) {
+      f |= kClsSpacing;
+      int lo = 0, hi = nsoft;  // sorted list of "soft" spacing chars (usually empty)
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (soft[mid] < c) lo = mid + 1; else hi = mid;
+      }
+      if (lo < nsoft && soft[lo] == c) f |= kClsSoft;
+    }
+    cls[out_base + k] = f;
+  }
+  if ((low_used[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1u) used[threadIdx.x] = 1u;
+}
+
+__global__ __launch_bounds__(kBlock) void mark_used_kernel(const uint32_t *__restrict__ cps, size_t n,
+                                                           uint32_t *__restrict__ used) {
+  size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) used[cps[i]] = 1u;
+  if (i == 0) used[1] = 1u;  // the separator (linear.cpp:92,99)
+}
+
+// sym[i] = dense, order-preserving symbol id (>= 1; 0 is reserved for "past the end")
+template <typename SymT>
+__global__ __launch_bounds__(kBlock) void map_symbols_kernel(const uint32_t *__restrict__ cps, size_t n_text,
+                                                             const uint32_t *__restrict__ vocab_cps, size_t n,
+                                                             const uint32_t *__restrict__ lut_excl,
+                                                             SymT *__restrict__ sym) {
+  size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  uint32_t c = i < n_text ? cps[i] : (i == n_text ? 1u : vocab_cps[i - n_text - 1]);
+  sym[i] = static_cast<SymT>(lut_excl[c] + 1u);
+}
+
+// Round-0 keys: the first K symbols of every suffix packed b bits each, most significant first.
+// Suffixes running past the end are padded with 0 (< every symbol), so shorter sorts first.
+constexpr int kKeyItems = 8;
+constexpr int kKeyTile = kBlock * kKeyItems;
+constexpr int kMaxK = 16;
+template <typename SymT>
+__global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restrict__ sym, size_t n, int K,
+                                                             int bits, uint64_t *__restrict__ keys,
+                                                             uint32_t *__restrict__ vals) {
+  __shared__ uint32_t ss[kKeyTile + kMaxK];
+  const size_t base = static_cast<size_t>(blockIdx.x) * kKeyTile;
+  for (int k = threadIdx.x; k < kKeyTile + kMaxK; k += kBlock) {
+    size_t i = base + k;
+    ss[k] = i < n ? static_cast<uint32_t>(sym[i]) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kKeyItems; j++) {
+    const int li = j * kBlock + threadIdx.x;
+    const size_t i = base + li;
+    if (i < n) {
+      uint64_t key = 0;
+      for (int k = 0; k < K; k++) key = (key << bits) | ss[li + k];
+      keys[i] = key;
+      vals[i] = static_cast<uint32_t>(i);
+    }
+  }
+}
+
+}  // namespace wp

@@ -1,0 +1,732 @@
+// encoder.hip — orchestration of the HIP Linear-WordPiece path and the C ABI (include/wordpiece_amd.h).
+//
+// Stages (reference file:line in parentheses):
+//   decode + classes + S build   utils.cpp:37-79, utf8.cpp:54-90, linear.cpp:77-103     decode.h
+//   suffix array / rank / LCP    linear.cpp:118-149 (libsais_int, inverse SA, calcLcp)   suffix_array.h, radix_sort.h
+//   who marks + 4 scanlines      linear.cpp:153-213                                        scanline.h
+//   greedy walk + id stream      linear.cpp:215-316                                        walk.h
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstring>
+#include <fstream>
+#include <memory>
+
+#include "../../include/wordpiece_amd.h"
+#include "decode.h"
+#include "radix_sort.h"
+#include "scanline.h"
+#include "suffix_array.h"
+#include "vocab.h"
+#include "walk.h"
+
+namespace wp {
+
+static thread_local std::string g_last_error;
+
+struct DeviceBuffer {
+  void *p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) WP_HIP(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + (1 << 20);
+    WP_HIP(hipMalloc(&p, want));
+    cap = want;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// bump allocator over a DeviceBuffer: plan() first with the same sequence of take() calls
+struct Arena {
+  DeviceBuffer *buf;
+  size_t off = 0;
+  bool planning = true;
+  explicit Arena(DeviceBuffer *b) : buf(b) {}
+  template <typename T>
+  T *take(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~static_cast<size_t>(255);
+    size_t o = off;
+    off += bytes;
+    if (planning) return nullptr;
+    return reinterpret_cast<T *>(static_cast<char *>(buf->p) + o);
+  }
+  void commit() {
+    buf->ensure(off);
+    off = 0;
+    planning = false;
+  }
+};
+
+static int bit_length(uint64_t v) {
+  int b = 0;
+  while (v) {
+    b++;
+    v >>= 1;
+  }
+  return b;
+}
+
+struct Context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // vocab tables on the device
+  uint32_t *d_stream = nullptr, *d_elig_start = nullptr, *d_elig_info = nullptr, *d_soft = nullptr;
+  int32_t *d_elig_id = nullptr, *d_tok_len = nullptr;
+  DeviceBuffer text_buf, a_buf, b_buf;
+  uint32_t *d_used = nullptr, *d_lut = nullptr, *d_scan_tmp = nullptr;  // code point tables
+  uint32_t *d_scalars = nullptr;                                         // 16 words of device scalars
+  uint32_t *h_scalars = nullptr;                                         // pinned mirror
+  RadixStats rstats;
+  hipEvent_t ev[8] = {};
+  // results / debug views of the last call (device pointers into the arenas)
+  const int32_t *d_ids = nullptr;
+  struct {
+    const void *sym = nullptr;
+    int sym_bytes = 0;
+    const uint32_t *sa = nullptr, *rank = nullptr, *cps = nullptr;
+    const int32_t *lcp = nullptr, *bestp = nullptr, *bests = nullptr;
+    size_t n = 0, n_text = 0;
+  } dbg;
+};
+
+}  // namespace wp
+
+using namespace wp;
+
+struct wp_vocab {
+  HostVocab hv;
+  std::unique_ptr<Context> ctx;
+  int device = -1;
+  bool full_depth = false, keep_debug = false, stage_timing = false, lcp_kasai = false;
+  wp_stats stats{};
+  ~wp_vocab();
+};
+
+namespace wp {
+
+static void destroy_context(Context *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (void *p : {static_cast<void *>(c->d_stream), static_cast<void *>(c->d_elig_start),
+                  static_cast<void *>(c->d_elig_info), static_cast<void *>(c->d_soft),
+                  static_cast<void *>(c->d_elig_id), static_cast<void *>(c->d_tok_len),
+                  static_cast<void *>(c->d_used), static_cast<void *>(c->d_lut), static_cast<void *>(c->d_scan_tmp),
+                  static_cast<void *>(c->d_scalars)}) {
+    if (p) (void)hipFree(p);
+  }
+  if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+  c->text_buf.release();
+  c->a_buf.release();
+  c->b_buf.release();
+  for (auto &e : c->ev) {
+    if (e) (void)hipEventDestroy(e);
+  }
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+template <typename T>
+static T *upload(const std::vector<T> &v, hipStream_t st) {
+  T *d = nullptr;
+  WP_HIP(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  if (!v.empty()) WP_HIP(hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  return d;
+}
+
+static Context *get_context(wp_vocab *v) {
+  if (v->ctx) {
+    WP_HIP(hipSetDevice(v->ctx->device));
+    return v->ctx.get();
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+    throw HipError("no HIP device available: the Linear WordPiece path has no CPU fallback");
+  }
+  std::unique_ptr<Context> c(new Context());
+  if (v->device >= 0) {
+    c->device = v->device;
+  } else {
+    WP_HIP(hipGetDevice(&c->device));
+  }
+  WP_HIP(hipSetDevice(c->device));
+  WP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  const HostVocab &hv = v->hv;
+  c->d_stream = upload(hv.stream, c->stream);
+  c->d_elig_start = upload(hv.elig_start, c->stream);
+  c->d_elig_info = upload(hv.elig_info, c->stream);
+  c->d_elig_id = upload(hv.elig_id, c->stream);
+  c->d_tok_len = upload(hv.tok_len, c->stream);
+  c->d_soft = upload(hv.soft, c->stream);
+  WP_HIP(hipMalloc(&c->d_used, sizeof(uint32_t) * kCpTableSize));
+  WP_HIP(hipMalloc(&c->d_lut, sizeof(uint32_t) * kCpTableSize));
+  WP_HIP(hipMalloc(&c->d_scan_tmp, sizeof(uint32_t) * (cdiv(kCpTableSize, kScanTile) + 8)));
+  WP_HIP(hipMalloc(&c->d_scalars, sizeof(uint32_t) * 16));
+  WP_HIP(hipHostMalloc(&c->h_scalars, sizeof(uint32_t) * 16));
+  for (auto &e : c->ev) WP_HIP(hipEventCreate(&e));
+  WP_HIP(hipStreamSynchronize(c->stream));
+  v->ctx = std::move(c);
+  return v->ctx.get();
+}
+
+// copies `count` device scalars (from d_scalars) to the pinned mirror and waits
+static void fetch_scalars(Context *c, int count) {
+  WP_HIP(hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, c->stream));
+  WP_HIP(hipStreamSynchronize(c->stream));
+}
+
+template <typename SymT>
+static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text, size_t n, const uint32_t *d_cps,
+                              const uint8_t *d_cls, int bits, size_t *n_ids_out);
+
+// The whole device path.  d_text must be 4-byte aligned and readable up to the next multiple of 4.
+static void encode_on_device(wp_vocab *v, const uint8_t *d_text, size_t nbytes, size_t *n_ids_out) {
+  Context *c = get_context(v);
+  hipStream_t st = c->stream;
+  const HostVocab &hv = v->hv;
+  wp_stats &S = v->stats;
+  std::memset(&S, 0, sizeof(S));
+  S.n_bytes = static_cast<int64_t>(nbytes);
+  S.longest_token = hv.longest;
+  c->d_ids = nullptr;
+  c->dbg = {};
+  *n_ids_out = 0;
+  if (nbytes == 0) return;  // linear.cpp:323-325
+  if (nbytes > 2000000000ull) throw std::length_error("64bit not implemented");
+
+  c->rstats.passes = 0;
+  c->rstats.elems = 0;
+  c->rstats.spans.on = v->stage_timing;
+  c->rstats.spans.used = 0;
+  if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[0], st));
+
+  // ---------------- phase A: decode ----------------
+  const unsigned dec_tiles = cdiv(nbytes, kDecTile);
+  Arena aa(&c->a_buf);
+  uint32_t *d_tile_cnt = nullptr, *d_cnt_tmp = nullptr, *d_cps = nullptr;
+  uint8_t *d_cls = nullptr;
+  for (int pass = 0; pass < 2; pass++) {
+    d_tile_cnt = aa.take<uint32_t>(dec_tiles + 1);
+    d_cnt_tmp = aa.take<uint32_t>(cdiv(dec_tiles, kScanTile) + 8);
+    d_cps = aa.take<uint32_t>(nbytes + 1);
+    d_cls = aa.take<uint8_t>(nbytes + 1);
+    if (pass == 0) aa.commit();
+  }
+  WP_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(uint32_t) * 16, st));
+  WP_HIP(hipMemsetAsync(c->d_used, 0, sizeof(uint32_t) * kCpTableSize, st));
+  hipLaunchKernelGGL(decode_count_kernel, dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes, d_tile_cnt,
+                     reinterpret_cast<unsigned long long *>(c->d_scalars + 2));
+  device_exclusive_scan(d_tile_cnt, d_tile_cnt, dec_tiles, d_cnt_tmp, c->d_scalars + 0, st);
+  hipLaunchKernelGGL(decode_write_kernel, dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes, d_tile_cnt, d_cps,
+                     d_cls, c->d_used, c->d_soft, static_cast<int>(hv.soft.size()));
+  hipLaunchKernelGGL(mark_used_kernel, dim3(cdiv(std::max<size_t>(hv.stream.size(), 1), kBlock)), dim3(kBlock), 0,
+                     st, c->d_stream, hv.stream.size(), c->d_used);
+  device_exclusive_scan(c->d_used, c->d_lut, kCpTableSize, c->d_scan_tmp, c->d_scalars + 1, st);
+  WP_LAUNCH_CHECK();
+  fetch_scalars(c, 4);
+  const size_t n_text = c->h_scalars[0];
+  const uint32_t sigma = c->h_scalars[1];
+  unsigned long long consumed;
+  std::memcpy(&consumed, c->h_scalars + 2, sizeof(consumed));
+  if (consumed != nbytes) std::cerr << "WARNING Input contains invalid unicode characters." << std::endl;
+
+  const size_t n = n_text + 1 + hv.stream.size();  // total_length, linear.cpp:77-82
+  S.n_text = static_cast<int64_t>(n_text);
+  S.n_total = static_cast<int64_t>(n);
+  S.alphabet = sigma;
+  if (n > 2000000000ull) throw std::length_error("64bit not implemented");  // linear.cpp:104-106
+  if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[1], st));
+
+  const int bits = std::max(1, bit_length(sigma));  // symbols are 1..sigma, 0 = past the end
+  Arena ab(&c->b_buf);
+  if (sigma <= 255) {
+    run_sa_and_beyond<uint8_t>(v, c, ab, n_text, n, d_cps, d_cls, bits, n_ids_out);
+  } else {
+    run_sa_and_beyond<uint32_t>(v, c, ab, n_text, n, d_cps, d_cls, bits, n_ids_out);
+  }
+}
+
+template <typename SymT>
+static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text, size_t n, const uint32_t *d_cps,
+                              const uint8_t *d_cls, int bits, size_t *n_ids_out) {
+  hipStream_t st = c->stream;
+  const HostVocab &hv = v->hv;
+  wp_stats &S = v->stats;
+  const int K = std::max(1, std::min(kMaxK, 64 / bits));
+  const bool full = v->full_depth || hv.n_dup_eligible > 0 || v->lcp_kasai;
+  const uint32_t need_depth = static_cast<uint32_t>(std::min<int64_t>(hv.longest + 1, 0x7fffffff));
+  S.symbol_bits = bits;
+  S.symbols_per_key = K;
+  S.full_depth = full;
+
+  const int M = static_cast<int>(hv.elig_id.size());
+  const unsigned sl_tiles = cdiv(n, kSlTile);
+  const int D = static_cast<int>(std::min<int64_t>(hv.longest + hv.n_dup_eligible + 1, std::max(M, 1)));
+  const size_t carry_lds = (2 * static_cast<size_t>(D) + 2 * kCarryWin) * sizeof(int32_t);
+  if (carry_lds > 160 * 1024 - 1024) throw std::length_error("vocabulary nesting too deep for the scan kernel");
+
+  const size_t rr_tiles = cdiv(n, kRrTile);
+  const size_t radix_words = std::max(radix_tmp_words<uint64_t>(n), radix_tmp_words<uint32_t>(std::max(M, 1)));
+  const size_t emit_tiles = cdiv(std::max<size_t>(n_text, 1), kScanTile);
+
+  SymT *d_sym = nullptr;
+  uint64_t *K0 = nullptr, *K1 = nullptr;
+  uint32_t *V0 = nullptr, *V1 = nullptr, *AS0 = nullptr, *AS1 = nullptr, *AG = nullptr, *d_sa = nullptr,
+           *d_rank = nullptr, *d_radix_tmp = nullptr, *d_mslot0 = nullptr, *d_mslot1 = nullptr, *d_midx0 = nullptr,
+           *d_midx1 = nullptr, *d_minfo = nullptr, *d_tile_mlo = nullptr, *d_depth = nullptr, *d_emit_cnt = nullptr,
+           *d_emit_tmp = nullptr;
+  int32_t *d_lcp = nullptr, *d_mid = nullptr, *d_interior = nullptr, *d_rf = nullptr, *d_rb = nullptr;
+  RerankAgg *d_agg = nullptr;
+  int2 *d_pool = nullptr;
+  for (int pass = 0; pass < 2; pass++) {
+    d_sym = ar.take<SymT>(n + 16);
+    K0 = ar.take<uint64_t>(n);
+    K1 = ar.take<uint64_t>(n);
+    V0 = ar.take<uint32_t>(n);
+    V1 = ar.take<uint32_t>(n);
+    AS0 = ar.take<uint32_t>(n);
+    AS1 = ar.take<uint32_t>(n);
+    AG = ar.take<uint32_t>(n);
+    d_sa = ar.take<uint32_t>(n);
+    d_rank = ar.take<uint32_t>(n);
+    d_lcp = ar.take<int32_t>(n);
+    d_radix_tmp = ar.take<uint32_t>(radix_words);
+    d_agg = ar.take<RerankAgg>(rr_tiles + 1);
+    d_mslot0 = ar.take<uint32_t>(M + 1);
+    d_mslot1 = ar.take<uint32_t>(M + 1);
+    d_midx0 = ar.take<uint32_t>(M + 1);
+    d_midx1 = ar.take<uint32_t>(M + 1);
+    d_mid = ar.take<int32_t>(M + 1);
+    d_minfo = ar.take<uint32_t>(M + 1);
+    d_rf = ar.take<int32_t>(M + 1);
+    d_rb = ar.take<int32_t>(M + 1);
+    d_tile_mlo = ar.take<uint32_t>(sl_tiles + 2);
+    d_interior = ar.take<int32_t>(sl_tiles + 1);
+    d_depth = ar.take<uint32_t>(4 * static_cast<size_t>(sl_tiles));
+    d_pool = ar.take<int2>(4 * static_cast<size_t>(sl_tiles) * D);
+    d_emit_cnt = ar.take<uint32_t>(emit_tiles + 1);
+    d_emit_tmp = ar.take<uint32_t>(cdiv(emit_tiles, kScanTile) + 8);
+    if (pass == 0) ar.commit();
+  }
+
+  // ---------------- S build: dense symbols, round-0 keys ----------------
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(map_symbols_kernel<SymT>), dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, d_cps,
+                     n_text, c->d_stream, n, c->d_lut, d_sym);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(build_keys0_kernel<SymT>), dim3(cdiv(n, kKeyTile)), dim3(kBlock), 0, st, d_sym,
+                     n, K, bits, K0, V0);
+  WP_LAUNCH_CHECK();
+  if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[2], st));
+
+  // ---------------- suffix array by prefix doubling ----------------
+  int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, K * bits, d_radix_tmp, st, &c->rstats);
+  uint64_t *keys = cur ? K1 : K0;
+  uint32_t *vals = cur ? V1 : V0, *other_vals = cur ? V0 : V1;
+  uint32_t *slots = AS0, *other_slots = AS1;
+  {
+    const unsigned tiles = cdiv(n, kRrTile);
+    hipLaunchKernelGGL(rerank_agg_kernel, dim3(tiles), dim3(kBlock), 0, st, keys, n, d_agg);
+    hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kBlock), 0, st, d_agg, static_cast<size_t>(tiles),
+                       c->d_scalars + 4);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
+                       vals, static_cast<const uint32_t *>(nullptr), n, d_agg, d_sym, n, 0u, K, bits, d_sa, d_rank,
+                       d_lcp, slots, other_vals, AG);
+    WP_LAUNCH_CHECK();
+  }
+  fetch_scalars(c, 6);
+  size_t n_act = c->h_scalars[4], n_groups = c->h_scalars[5];
+  uint64_t depth = static_cast<uint64_t>(K);
+  int rounds = 1;
+  S.active_per_round[0] = static_cast<int64_t>(n);
+  uint32_t *avals = other_vals;  // active list values live in the vals buffer the sort did not end in
+  uint32_t *spare_vals = vals;
+  while (n_act > 0 && (full || depth < need_depth)) {
+    if (rounds < 40) S.active_per_round[rounds] = static_cast<int64_t>(n_act);
+    const uint32_t h = static_cast<uint32_t>(std::min<uint64_t>(depth, 0x7fffffffu));
+    hipLaunchKernelGGL(build_keys_round_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, avals, AG, n_act,
+                       d_rank, h, n, K0);
+    const int rb = bit_length(n);  // rank+1 <= n
+    const int gb = bit_length(n_groups > 0 ? n_groups - 1 : 0);
+    int cc = radix_sort_pairs<uint64_t>(K0, avals, K1, spare_vals, n_act, 0, rb, d_radix_tmp, st, &c->rstats, 0);
+    if (gb > 0) cc = radix_sort_pairs<uint64_t>(K0, avals, K1, spare_vals, n_act, 32, 32 + gb, d_radix_tmp, st, &c->rstats, cc);
+    uint64_t *skeys = cc ? K1 : K0;
+    uint32_t *svals = cc ? spare_vals : avals;
+    uint32_t *nvals = cc ? avals : spare_vals;
+    const unsigned tiles = cdiv(n_act, kRrTile);
+    hipLaunchKernelGGL(rerank_agg_kernel, dim3(tiles), dim3(kBlock), 0, st, skeys, n_act, d_agg);
+    hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kBlock), 0, st, d_agg, static_cast<size_t>(tiles),
+                       c->d_scalars + 4);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
+                       svals, slots, n_act, d_agg, d_sym, n, h, K, bits, d_sa, d_rank, d_lcp, other_slots, nvals, AG);
+    WP_LAUNCH_CHECK();
+    fetch_scalars(c, 6);
+    n_act = c->h_scalars[4];
+    n_groups = c->h_scalars[5];
+    std::swap(slots, other_slots);
+    avals = nvals;
+    spare_vals = svals;
+    depth *= 2;
+    rounds++;
+  }
+  S.rounds = rounds;
+  S.sorted_depth = static_cast<int32_t>(std::min<uint64_t>(depth, 0x7fffffffu));
+  if (n_act == 0) S.sorted_depth = 0x7fffffff;
+  if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[3], st));
+
+  if (v->lcp_kasai) {  // alternative LCP builder: chunked Kasai exactly as linear.cpp:18-70
+    const size_t chunk = 64;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(kasai_kernel<SymT>), dim3(cdiv(cdiv(n, chunk), kBlock)), dim3(kBlock), 0, st,
+                       d_sym, d_sa, d_rank, n, chunk, d_lcp);
+    WP_LAUNCH_CHECK();
+  }
+  if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[4], st));
+
+  // ---------------- who marks + scanlines ----------------
+  int32_t *d_bestp = reinterpret_cast<int32_t *>(K0), *d_bests = reinterpret_cast<int32_t *>(K0) + n;
+  {
+    const size_t vocab_base = n_text + 1;
+    uint32_t *mslot = d_mslot0, *midx = d_midx0;
+    if (M > 0) {
+      hipLaunchKernelGGL(mark_slots_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, c->d_elig_start, M,
+                         vocab_base, d_rank, d_mslot0, d_midx0);
+      int mc = radix_sort_pairs<uint32_t>(d_mslot0, d_midx0, d_mslot1, d_midx1, M, 0, bit_length(n), d_radix_tmp,
+                                          st, nullptr);
+      mslot = mc ? d_mslot1 : d_mslot0;
+      midx = mc ? d_midx1 : d_midx0;
+      hipLaunchKernelGGL(mark_gather_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, midx, M, c->d_elig_id,
+                         c->d_elig_info, d_mid, d_minfo);
+    }
+    hipLaunchKernelGGL(tile_mlo_kernel, dim3(cdiv(sl_tiles + 1, kBlock)), dim3(kBlock), 0, st, mslot, M, n, sl_tiles,
+                       d_tile_mlo);
+    hipLaunchKernelGGL(sl_summary_kernel, dim3(sl_tiles), dim3(kBlock), 0, st, d_lcp, n, mslot, d_minfo, d_tile_mlo,
+                       d_interior, d_rf, d_rb);
+    if (carry_lds > 48 * 1024) {
+      WP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sl_carry_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(carry_lds)));
+    }
+    hipLaunchKernelGGL(sl_carry_kernel, dim3(4), dim3(kWave), carry_lds, st, d_lcp, n, sl_tiles, d_interior,
+                       d_tile_mlo, d_mid, d_minfo, M, D, d_pool, d_depth, c->d_scalars + 8);
+    hipLaunchKernelGGL(sl_resolve_kernel, dim3(sl_tiles), dim3(kBlock), 0, st, d_lcp, n, sl_tiles, d_tile_mlo, mslot,
+                       d_mid, d_minfo, d_rf, d_rb, d_pool, d_depth, D, d_bestp, d_bests);
+    WP_LAUNCH_CHECK();
+  }
+  if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[5], st));
+
+  // ---------------- greedy walk + id stream ----------------
+  int32_t *d_emit = reinterpret_cast<int32_t *>(V0);
+  int32_t *d_ids = reinterpret_cast<int32_t *>(V1);
+  size_t n_ids = 0;
+  if (n_text > 0) {
+    WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st));
+    WalkArgs wa{d_cls, n_text, d_rank, d_bestp, d_bests, c->d_tok_len, hv.unk_id, d_emit};
+    hipLaunchKernelGGL(walk_kernel, dim3(cdiv(n_text, kBlock)), dim3(kBlock), 0, st, wa);
+    const unsigned tiles = cdiv(n_text, kScanTile);
+    hipLaunchKernelGGL(emit_count_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt);
+    device_exclusive_scan(d_emit_cnt, d_emit_cnt, tiles, d_emit_tmp, c->d_scalars + 9, st);
+    hipLaunchKernelGGL(emit_write_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt, d_ids);
+    WP_LAUNCH_CHECK();
+  }
+  if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[6], st));
+  fetch_scalars(c, 10);
+  if (c->h_scalars[8]) throw std::length_error("scan stack overflow (vocabulary nesting deeper than expected)");
+  n_ids = n_text > 0 ? c->h_scalars[9] : 0;
+
+  S.n_ids = static_cast<int64_t>(n_ids);
+  S.radix_passes = c->rstats.passes;
+  S.radix_pass_elems = c->rstats.elems;
+  if (v->stage_timing) {
+    auto span = [&](int a, int b) {
+      float ms = 0;
+      WP_HIP(hipEventElapsedTime(&ms, c->ev[a], c->ev[b]));
+      return static_cast<double>(ms);
+    };
+    S.ms_decode = span(0, 2);
+    S.ms_sa = span(2, 3);
+    S.ms_lcp = span(3, 4);
+    S.ms_scan = span(4, 5);
+    S.ms_walk = span(5, 6);
+    S.ms_total = span(0, 6);
+    S.ms_radix_scatter = c->rstats.spans.resolve();
+  }
+  c->d_ids = d_ids;
+  c->dbg.sym = d_sym;
+  c->dbg.sym_bytes = sizeof(SymT);
+  c->dbg.sa = d_sa;
+  c->dbg.rank = d_rank;
+  c->dbg.lcp = d_lcp;
+  c->dbg.bestp = d_bestp;
+  c->dbg.bests = d_bests;
+  c->dbg.cps = d_cps;
+  c->dbg.n = n;
+  c->dbg.n_text = n_text;
+  *n_ids_out = n_ids;
+}
+
+}  // namespace wp
+
+wp_vocab::~wp_vocab() { destroy_context(ctx.get()); }
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+template <typename F>
+static int guarded(F &&f) {
+  try {
+    f();
+    return WP_OK;
+  } catch (const HipError &e) {
+    g_last_error = e.what();
+    return std::string(e.what()).find("no HIP device") != std::string::npos ? WP_ERR_NO_DEVICE : WP_ERR_HIP;
+  } catch (const std::length_error &e) {
+    g_last_error = e.what();
+    return WP_ERR_TOO_LARGE;
+  } catch (const std::invalid_argument &e) {
+    g_last_error = e.what();
+    return WP_ERR_ARG;
+  } catch (const std::ios_base::failure &e) {
+    g_last_error = e.what();
+    return WP_ERR_IO;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return WP_ERR_HIP;
+  }
+}
+
+static int vocab_from_lines(const std::vector<std::pair<const char *, size_t>> &lines, wp_vocab **out) {
+  if (!out) {
+    g_last_error = "null output pointer";
+    return WP_ERR_ARG;
+  }
+  std::unique_ptr<wp_vocab> v(new wp_vocab());
+  std::string err = v->hv.build(lines);
+  if (!err.empty()) {
+    g_last_error = err;
+    return WP_ERR_EMPTY_WORD;
+  }
+  *out = v.release();
+  return WP_OK;
+}
+
+extern "C" {
+
+int wp_vocab_create(const char *const *lines, const size_t *line_bytes, size_t n_lines, wp_vocab **out) {
+  std::vector<std::pair<const char *, size_t>> ls;
+  ls.reserve(n_lines);
+  for (size_t i = 0; i < n_lines; i++) ls.emplace_back(lines[i], line_bytes[i]);
+  return vocab_from_lines(ls, out);
+}
+
+int wp_vocab_create_packed(const char *buf, const int64_t *offsets, int64_t n_lines, wp_vocab **out) {
+  std::vector<std::pair<const char *, size_t>> ls;
+  ls.reserve(static_cast<size_t>(n_lines));
+  for (int64_t i = 0; i < n_lines; i++) ls.emplace_back(buf + offsets[i], static_cast<size_t>(offsets[i + 1] - offsets[i]));
+  return vocab_from_lines(ls, out);
+}
+
+int wp_vocab_from_file(const char *vocab_file, wp_vocab **out) {
+  // utils.cpp:123-137: a missing file yields an empty vocabulary (ifstream fails silently)
+  std::ifstream fin(vocab_file);
+  std::vector<std::string> words;
+  std::string w;
+  while (std::getline(fin, w)) words.push_back(w);
+  std::vector<std::pair<const char *, size_t>> ls;
+  for (auto &s : words) ls.emplace_back(s.data(), s.size());
+  return vocab_from_lines(ls, out);
+}
+
+void wp_vocab_destroy(wp_vocab *v) { delete v; }
+int64_t wp_vocab_size(const wp_vocab *v) { return static_cast<int64_t>(v->hv.tokens.size()); }
+int32_t wp_vocab_unk_id(const wp_vocab *v) { return v->hv.unk_id; }
+int32_t wp_vocab_token_flags(const wp_vocab *v, int64_t i) {
+  const HostToken &t = v->hv.tokens[static_cast<size_t>(i)];
+  return (t.is_prefix ? 1 : 0) | (t.is_special ? 2 : 0) | (t.is_malformed ? 4 : 0);
+}
+int64_t wp_vocab_token_len(const wp_vocab *v, int64_t i) {
+  return static_cast<int64_t>(v->hv.tokens[static_cast<size_t>(i)].word.size());
+}
+
+int wp_set_option(wp_vocab *v, int option, int64_t value) {
+  switch (option) {
+    case WP_OPT_FULL_DEPTH: v->full_depth = value != 0; return WP_OK;
+    case WP_OPT_DEVICE:
+      if (v->ctx) {
+        g_last_error = "device already bound";
+        return WP_ERR_ARG;
+      }
+      v->device = static_cast<int>(value);
+      return WP_OK;
+    case WP_OPT_KEEP_DEBUG: v->keep_debug = value != 0; return WP_OK;
+    case WP_OPT_STAGE_TIMING: v->stage_timing = value != 0; return WP_OK;
+    case WP_OPT_LCP_KASAI: v->lcp_kasai = value != 0; return WP_OK;
+  }
+  g_last_error = "unknown option";
+  return WP_ERR_ARG;
+}
+
+int wp_get_stats(const wp_vocab *v, wp_stats *out) {
+  *out = v->stats;
+  return WP_OK;
+}
+
+int wp_linear_encode_device(wp_vocab *v, const void *d_utf8, size_t nbytes, const int32_t **d_ids, size_t *n_ids) {
+  return guarded([&] {
+    if ((reinterpret_cast<uintptr_t>(d_utf8) & 3u) != 0) throw std::invalid_argument("device text must be 4-byte aligned");
+    size_t n = 0;
+    encode_on_device(v, static_cast<const uint8_t *>(d_utf8), nbytes, &n);
+    *d_ids = n ? v->ctx->d_ids : nullptr;
+    *n_ids = n;
+  });
+}
+
+int wp_linear_encode(wp_vocab *v, const char *utf8, size_t nbytes, int32_t **ids, size_t *n_ids) {
+  return guarded([&] {
+    *ids = nullptr;
+    *n_ids = 0;
+    if (nbytes == 0) return;  // linear.cpp:323-325: the vocab path is not touched
+    Context *c = get_context(v);
+    c->text_buf.ensure(nbytes + 64);
+    WP_HIP(hipMemsetAsync(static_cast<char *>(c->text_buf.p) + (nbytes & ~static_cast<size_t>(15)), 0, 32, c->stream));
+    WP_HIP(hipMemcpyAsync(c->text_buf.p, utf8, nbytes, hipMemcpyHostToDevice, c->stream));
+    size_t n = 0;
+    encode_on_device(v, static_cast<const uint8_t *>(c->text_buf.p), nbytes, &n);
+    if (n) {
+      int32_t *h = static_cast<int32_t *>(std::malloc(n * sizeof(int32_t)));
+      if (!h) throw std::runtime_error("out of host memory");
+      WP_HIP(hipMemcpyAsync(h, c->d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      WP_HIP(hipStreamSynchronize(c->stream));
+      *ids = h;
+      *n_ids = n;
+    }
+  });
+}
+
+struct MappedFile {
+  const char *data = nullptr;
+  size_t size = 0;
+  int fd = -1;
+  explicit MappedFile(const char *path) {
+    fd = ::open(path, O_RDONLY);
+    if (fd < 0) throw std::ios_base::failure(std::string("cannot open ") + path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) {
+      ::close(fd);
+      throw std::ios_base::failure(std::string("cannot stat ") + path);
+    }
+    size = static_cast<size_t>(sb.st_size);
+    if (size) {
+      void *p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (p == MAP_FAILED) {
+        ::close(fd);
+        throw std::ios_base::failure(std::string("cannot mmap ") + path);
+      }
+      data = static_cast<const char *>(p);
+    }
+  }
+  ~MappedFile() {
+    if (data) munmap(const_cast<char *>(data), size);
+    if (fd >= 0) ::close(fd);
+  }
+};
+
+int wp_linear_encode_file(const char *text_file, const char *vocab_file, int32_t **ids, size_t *n_ids) {
+  wp_vocab *v = nullptr;
+  int rc = wp_vocab_from_file(vocab_file, &v);
+  if (rc != WP_OK) return rc;
+  std::unique_ptr<wp_vocab> guard(v);
+  rc = guarded([&] {
+    MappedFile mm(text_file);
+    int r2 = wp_linear_encode(v, mm.data, mm.size, ids, n_ids);
+    if (r2 != WP_OK) throw std::runtime_error(g_last_error);
+  });
+  return rc;
+}
+
+int wp_linear_encode_external(const char *text_file, const char *vocab_file, const char *out_file,
+                              size_t memory_limit) {
+  wp_vocab *v = nullptr;
+  int rc = wp_vocab_from_file(vocab_file, &v);
+  if (rc != WP_OK) return rc;
+  std::unique_ptr<wp_vocab> guard(v);
+  return guarded([&] {
+    const size_t max_batch = memory_limit / 20;  // linear.cpp:349
+    if (max_batch == 0) throw std::invalid_argument("memory_limit too small");
+    MappedFile mm(text_file);
+    const char *begin = mm.data;
+    size_t size = mm.size;
+    std::ofstream fout(out_file);
+    std::string chunk;
+    while (size > 0) {
+      size_t batch;
+      if (size > max_batch) {  // linear.cpp:357-362: grow until the batch's last byte starts a space
+        batch = max_batch;
+        while (batch < size) {
+          const uint8_t *p = reinterpret_cast<const uint8_t *>(begin + batch - 1);
+          uint32_t cp = ((p[0] & 0xc0u) == 0x80u) ? kInvalidUnicode : decode_one(p, static_cast<int64_t>(size - batch));
+          if (is_space(cp)) break;
+          batch++;
+        }
+      } else {
+        batch = size;
+      }
+      int32_t *ids = nullptr;
+      size_t n = 0;
+      if (wp_linear_encode(v, begin, batch, &ids, &n) != WP_OK) throw std::runtime_error(g_last_error);
+      chunk.clear();
+      for (size_t i = 0; i < n; i++) {  // utils.cpp:30-35 format: "<id> "
+        chunk += std::to_string(ids[i]);
+        chunk += ' ';
+      }
+      fout.write(chunk.data(), static_cast<std::streamsize>(chunk.size()));
+      std::free(ids);
+      begin += batch;
+      size -= batch;
+    }
+  });
+}
+
+int wp_linear_debug_fetch(const wp_vocab *v, int which, int32_t *out, size_t capacity, size_t *n_out) {
+  return guarded([&] {
+    if (!v->ctx || v->ctx->dbg.n == 0) throw std::invalid_argument("no encode has run on this handle");
+    Context *c = v->ctx.get();
+    WP_HIP(hipSetDevice(c->device));
+    const auto &d = c->dbg;
+    const void *src = nullptr;
+    size_t cnt = d.n;
+    switch (which) {
+      case 0: src = d.sym; break;
+      case 1: src = d.sa; break;
+      case 2: src = d.rank; break;
+      case 3: src = d.lcp; cnt = d.n - 1; break;
+      case 4: src = d.bestp; break;
+      case 5: src = d.bests; break;
+      case 6: src = d.cps; cnt = d.n_text; break;
+      default: throw std::invalid_argument("unknown debug array");
+    }
+    if (cnt > capacity) throw std::invalid_argument("debug buffer too small");
+    *n_out = cnt;
+    if (cnt == 0) return;
+    if (which == 0 && d.sym_bytes == 1) {
+      std::vector<uint8_t> tmp(cnt);
+      WP_HIP(hipMemcpy(tmp.data(), src, cnt, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < cnt; i++) out[i] = tmp[i];
+    } else {
+      WP_HIP(hipMemcpy(out, src, cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+  });
+}
+
+void wp_free(void *p) { std::free(p); }
+const char *wp_last_error(void) { return g_last_error.c_str(); }
+int wp_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+}  // extern "C"

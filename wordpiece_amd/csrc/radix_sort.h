@@ -1,0 +1,226 @@
+// radix_sort.h — stable LSD radix sort of (key, uint32 value) pairs, 8-bit digits.
+//
+// One pass = histogram kernel + scan + scatter kernel.  A tile is 256 threads x ITEMS
+// keys.  Inside a tile each wave ranks its keys with a wave64 match-any (ballot per digit
+// bit) against per-wave digit counters staged in LDS, the tile is reordered through LDS and
+// written back so that every digit run is a coalesced segment.  HBM traffic per pass and
+// element: sizeof(Key) (histogram) + 2*(sizeof(Key)+4) (scatter).
+#pragma once
+#include <vector>
+
+#include "primitives.h"
+
+namespace wp {
+
+constexpr int kRadixBits = 8;
+constexpr int kRadixBins = 1 << kRadixBits;
+
+template <typename KeyT>
+struct RadixCfg {
+  static constexpr int kItems = sizeof(KeyT) == 8 ? 12 : 16;
+  static constexpr int kTile = kBlock * kItems;
+};
+
+__device__ __forceinline__ uint64_t wave_match_any8(uint32_t digit) {
+  uint64_t peers = ~0ull;
+#pragma unroll
+  for (int b = 0; b < kRadixBits; b++) {
+    const bool bit = (digit >> b) & 1u;
+    const uint64_t m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+// hist[digit * ntiles + tile] = number of keys of this tile with that digit
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restrict__ keys, size_t n,
+                                                            int begin_bit, uint32_t mask,
+                                                            uint32_t *__restrict__ hist, unsigned ntiles) {
+  constexpr int ITEMS = RadixCfg<KeyT>::kItems;
+  __shared__ uint32_t sh[kRadixBins];
+  sh[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t base = static_cast<size_t>(blockIdx.x) * RadixCfg<KeyT>::kTile;
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    size_t i = base + static_cast<size_t>(j) * kBlock + threadIdx.x;
+    if (i < n) {
+      uint32_t d = static_cast<uint32_t>(keys[i] >> begin_bit) & mask;
+      atomicAdd(&sh[d], 1u);
+    }
+  }
+  __syncthreads();
+  hist[static_cast<size_t>(threadIdx.x) * ntiles + blockIdx.x] = sh[threadIdx.x];
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
+    const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
+    uint32_t *__restrict__ vout, size_t n, int begin_bit, uint32_t mask,
+    const uint32_t *__restrict__ goff, unsigned ntiles) {
+  constexpr int ITEMS = RadixCfg<KeyT>::kItems;
+  constexpr int TILE = RadixCfg<KeyT>::kTile;
+  constexpr int WAVES = kBlock / kWave;
+  __shared__ uint32_t wcnt[WAVES][kRadixBins];
+  __shared__ uint32_t dstart[kRadixBins];
+  __shared__ uint32_t gbase[kRadixBins];
+  __shared__ uint32_t ssum[8];
+  __shared__ KeyT skeys[TILE];
+  __shared__ uint32_t svals[TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t tile_base = static_cast<size_t>(blockIdx.x) * TILE;
+  const size_t wave_base = tile_base + static_cast<size_t>(w) * (kWave * ITEMS);
+  const uint32_t tile_count = static_cast<uint32_t>(min(static_cast<size_t>(TILE), n - tile_base));
+
+#pragma unroll
+  for (int i = 0; i < WAVES; i++) wcnt[i][tid] = 0;
+  __syncthreads();
+
+  KeyT key[ITEMS];
+  uint32_t val[ITEMS];
+  uint32_t rnk[ITEMS];
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
+    const bool valid = i < n;
+    key[r] = valid ? kin[i] : static_cast<KeyT>(~static_cast<KeyT>(0));
+    val[r] = valid ? vin[i] : 0u;
+  }
+  volatile uint32_t *mycnt = wcnt[w];
+  const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
+    // out-of-range slots (only at the very end of the last tile) take the top bin: they are the
+    // last keys in tile order, hence rank after every valid key and are never written back
+    const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : (kRadixBins - 1);
+    const uint64_t peers = wave_match_any8(d);
+    const int leader = __ffsll(static_cast<long long>(peers)) - 1;
+    uint32_t old = 0;
+    if (lane == leader) {
+      old = mycnt[d];
+      mycnt[d] = old + __popcll(peers);
+    }
+    old = __shfl(old, leader, kWave);
+    rnk[r] = old + __popcll(peers & lt);
+  }
+  __syncthreads();
+  // per digit (thread = digit): exclusive scan across waves, then across digits
+  uint32_t tot = 0;
+#pragma unroll
+  for (int i = 0; i < WAVES; i++) {
+    uint32_t c = wcnt[i][tid];
+    wcnt[i][tid] = tot;
+    tot += c;
+  }
+  uint32_t all;
+  uint32_t ds = block_excl_sum(tot, ssum, all);
+  dstart[tid] = ds;
+  gbase[tid] = goff[static_cast<size_t>(tid) * ntiles + blockIdx.x] - ds;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
+    const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : (kRadixBins - 1);
+    const uint32_t pos = dstart[d] + wcnt[w][d] + rnk[r];
+    skeys[pos] = key[r];
+    svals[pos] = val[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    const uint32_t k = static_cast<uint32_t>(j) * kBlock + tid;
+    if (k < tile_count) {
+      const KeyT kk = skeys[k];
+      const uint32_t d = static_cast<uint32_t>(kk >> begin_bit) & mask;
+      const size_t o = static_cast<size_t>(gbase[d]) + k;
+      kout[o] = kk;
+      vout[o] = svals[k];
+    }
+  }
+}
+
+// Brackets kernels with HIP events on their own stream without synchronising; resolve() is
+// called once after the whole encode has been synchronised.
+struct EventSpans {
+  bool on = false;
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+  void begin(hipStream_t st) {
+    if (!on) return;
+    if (used + 2 > ev.size()) {
+      for (int i = 0; i < 64; i++) {
+        hipEvent_t e;
+        WP_HIP(hipEventCreate(&e));
+        ev.push_back(e);
+      }
+    }
+    WP_HIP(hipEventRecord(ev[used], st));
+  }
+  void end(hipStream_t st) {
+    if (!on) return;
+    WP_HIP(hipEventRecord(ev[used + 1], st));
+    used += 2;
+  }
+  double resolve() {  // total ms over all spans; resets
+    double tot = 0;
+    for (size_t i = 0; i + 1 < used; i += 2) {
+      float ms = 0;
+      WP_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+      tot += ms;
+    }
+    used = 0;
+    return tot;
+  }
+  ~EventSpans() {
+    for (auto e : ev) (void)hipEventDestroy(e);
+  }
+};
+
+struct RadixStats {
+  int passes = 0;
+  long long elems = 0;
+  EventSpans spans;  // around every scatter launch
+};
+
+template <typename KeyT>
+size_t radix_tmp_words(size_t n) {
+  size_t ntiles = cdiv(n, RadixCfg<KeyT>::kTile);
+  size_t h = ntiles * kRadixBins;
+  return h + cdiv(h, kScanTile) + 8;
+}
+
+// Sorts bits [begin_bit, end_bit) of the keys (stable).  Data ping-pongs between (k0,v0) and
+// (k1,v1); returns 0 or 1 = which pair holds the result.  tmp: radix_tmp_words<KeyT>(n) uint32.
+template <typename KeyT>
+int radix_sort_pairs(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, int begin_bit, int end_bit,
+                     uint32_t *tmp, hipStream_t st, RadixStats *stats, int cur = 0) {
+  if (n == 0) return cur;
+  const unsigned ntiles = cdiv(n, RadixCfg<KeyT>::kTile);
+  const size_t h = static_cast<size_t>(ntiles) * kRadixBins;
+  uint32_t *hist = tmp, *scan_tmp = tmp + h;
+  for (int b = begin_bit; b < end_bit; b += kRadixBits) {
+    const int nb = min(kRadixBits, end_bit - b);
+    const uint32_t mask = (1u << nb) - 1u;
+    KeyT *ki = cur ? k1 : k0, *ko = cur ? k0 : k1;
+    uint32_t *vi = cur ? v1 : v0, *vo = cur ? v0 : v1;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, n, b,
+                       mask, hist, ntiles);
+    device_exclusive_scan(hist, hist, h, scan_tmp, nullptr, st);
+    if (stats) stats->spans.begin(st);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, vi,
+                       ko, vo, n, b, mask, hist, ntiles);
+    WP_LAUNCH_CHECK();
+    if (stats) {
+      stats->spans.end(st);
+      stats->passes++;
+      stats->elems += static_cast<long long>(n);
+    }
+    cur ^= 1;
+  }
+  return cur;
+}
+
+}  // namespace wp

@@ -1,0 +1,127 @@
+// vocab.h — host-side vocabulary model (utils.cpp:81-146 of the reference) and the derived
+// tables the device path needs.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <iostream>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "common.h"
+
+namespace wp {
+
+struct HostToken {
+  bool is_prefix = true, is_special = false, is_malformed = false;
+  std::vector<uint32_t> word;
+};
+
+inline std::vector<uint32_t> host_decode_utf8(const char *s, size_t nbytes, bool warn = true) {
+  // utf8.cpp:130-147: invalid bytes are dropped one at a time
+  std::vector<uint32_t> out;
+  out.reserve(nbytes / 4 + 4);
+  bool invalid = false;
+  size_t pos = 0;
+  const uint8_t *b = reinterpret_cast<const uint8_t *>(s);
+  while (pos < nbytes) {
+    if ((b[pos] & 0xc0u) == 0x80u) {  // stray continuation byte: utf_length == 0
+      invalid = true;
+      pos++;
+      continue;
+    }
+    uint32_t cp = decode_one(b + pos, static_cast<int64_t>(nbytes - pos));
+    if (cp == kInvalidUnicode) {
+      invalid = true;
+      pos++;
+    } else {
+      out.push_back(cp);
+      pos += cp < 0x80 ? 1 : cp < 0x800 ? 2 : cp < 0x10000 ? 3 : 4;
+    }
+  }
+  if (invalid && warn) std::cerr << "WARNING Input contains invalid unicode characters." << std::endl;
+  return out;
+}
+
+struct HostVocab {
+  std::vector<HostToken> tokens;
+  int32_t unk_id = -1;  // utils.hpp:30-33
+  int64_t longest = 1;  // longest_word_vocab, linear.cpp:78-82
+
+  // derived
+  std::vector<uint32_t> stream;      // tok0 · 1 · tok1 · 1 · ...  (code points, linear.cpp:93-100)
+  std::vector<uint32_t> elig_start;  // offset in `stream` of every eligible token
+  std::vector<int32_t> elig_id;      // its vocab line index
+  std::vector<uint32_t> elig_info;   // len | class << 30  (class 1 = ## suffix token)
+  std::vector<int32_t> tok_len;      // per vocab line
+  std::vector<uint32_t> soft;        // sorted spacing chars occurring inside eligible multi-char tokens
+  int64_t n_dup_eligible = 0;        // eligible tokens that repeat an earlier (class, word)
+
+  // returns "" or the error message (utils.cpp:99-101)
+  std::string build(const std::vector<std::pair<const char *, size_t>> &lines) {
+    tokens.clear();
+    tokens.reserve(lines.size());
+    int32_t id = 0;
+    for (auto &ln : lines) {
+      if (ln.second == 5 && std::string(ln.first, 5) == "[UNK]") unk_id = id;  // utils.cpp:113-115
+      HostToken t;
+      t.word = host_decode_utf8(ln.first, ln.second);
+      auto &w = t.word;
+      if (w.size() >= 2 && w[0] == '#' && w[1] == '#') {  // utils.cpp:139-141
+        t.is_prefix = false;
+        w.erase(w.begin(), w.begin() + 2);
+      } else if (w.size() > 2 && w[0] == '[' && w.back() == ']') {  // utils.cpp:143-146
+        t.is_special = true;
+      }
+      bool all_punct = true;
+      for (uint32_t c : w) {
+        if (c == kInvalidUnicode) t.is_malformed = true;
+        if (!is_punctuation(c) && !is_space(c)) all_punct = false;
+      }
+      if (w.empty()) return "Vocab word is empty";
+      if (t.is_malformed || (all_punct && w.size() > 1)) {
+        t.is_malformed = true;
+        std::cerr << "Vocab word is malformed: " << std::string(ln.first, ln.second) << std::endl;
+      }
+      tokens.push_back(std::move(t));
+      ++id;
+    }
+    derive();
+    return "";
+  }
+
+  void derive() {
+    stream.clear();
+    elig_start.clear();
+    elig_id.clear();
+    elig_info.clear();
+    tok_len.clear();
+    soft.clear();
+    longest = 1;
+    n_dup_eligible = 0;
+    std::map<std::pair<bool, std::vector<uint32_t>>, int> seen;
+    for (size_t i = 0; i < tokens.size(); i++) {
+      const HostToken &t = tokens[i];
+      longest = std::max<int64_t>(longest, static_cast<int64_t>(t.word.size()));
+      tok_len.push_back(static_cast<int32_t>(t.word.size()));
+      if (!t.is_special && !t.is_malformed) {  // linear.cpp:179
+        elig_start.push_back(static_cast<uint32_t>(stream.size()));
+        elig_id.push_back(static_cast<int32_t>(i));
+        elig_info.push_back(static_cast<uint32_t>(t.word.size()) | (t.is_prefix ? 0u : 1u) << 30);
+        if (++seen[{t.is_prefix, t.word}] > 1) n_dup_eligible++;
+        if (t.word.size() > 1) {
+          for (uint32_t c : t.word) {
+            if (is_spacing_char(c)) soft.push_back(c);
+          }
+        }
+      }
+      stream.insert(stream.end(), t.word.begin(), t.word.end());
+      stream.push_back(1);
+    }
+    std::sort(soft.begin(), soft.end());
+    soft.erase(std::unique(soft.begin(), soft.end()), soft.end());
+  }
+};
+
+}  // namespace wp

@@ -1,0 +1,120 @@
+// walk.h — the greedy WordPiece walk (linear.cpp:215-274 match_word_piece) and id compaction.
+//
+// The reference walks the text sequentially (per thread chunk).  The walk's state is memoryless
+// whenever it stands on a word-prefix position (tokens_since_prefix == 0), and a position q is
+// *certain* to be visited when it is a non-space word-prefix position whose spacing neighbour can
+// never lie inside a longer match — i.e. that spacing char does not occur inside any eligible
+// multi-char vocab token ("hard" spacing char; for every sane vocabulary all of them are hard).
+// Such positions are anchors: one thread starts at each anchor and walks until it reaches the
+// next one, so the union of all threads' steps is exactly the reference's sequential walk.
+// Tokens are emitted into a text-order array (one slot per code point) and stream-compacted.
+#pragma once
+#include "primitives.h"
+
+namespace wp {
+
+constexpr int32_t kNoEmit = static_cast<int32_t>(0x80808080u);  // hipMemset(0x80) pattern; ids are >= -1
+
+struct WalkArgs {
+  const uint8_t *cls;
+  size_t n_text;
+  const uint32_t *rank;
+  const int32_t *best_prefix, *best_suffix;
+  const int32_t *tok_len;
+  int32_t unk_id;
+  int32_t *emit;
+};
+
+__device__ __forceinline__ bool w_space(const WalkArgs &a, size_t p) { return a.cls[p] & kClsSpace; }
+__device__ __forceinline__ bool w_word_prefix(const WalkArgs &a, size_t p) {  // linear.cpp:215-219
+  return p == 0 || (a.cls[p] & kClsSpacing) || (a.cls[p - 1] & kClsSpacing);
+}
+__device__ __forceinline__ bool w_hard(uint8_t c) { return (c & kClsSpacing) && !(c & kClsSoft); }
+__device__ __forceinline__ bool w_anchor(const WalkArgs &a, size_t p) {
+  const uint8_t c = a.cls[p];
+  if (c & kClsSpace) return false;
+  return p == 0 || w_hard(c) || w_hard(a.cls[p - 1]);
+}
+
+__device__ inline void walk_from(const WalkArgs &a, size_t p) {
+  const size_t end = a.n_text;
+  size_t since = p;  // start of the tokens counted by tokens_since_prefix
+  while (p < end) {
+    const bool prefix = w_word_prefix(a, p);
+    const uint32_t r = a.rank[p];
+    const int32_t id = prefix ? a.best_prefix[r] : a.best_suffix[r];
+    if (id != -1) {
+      a.emit[p] = id;
+      p += static_cast<size_t>(a.tok_len[id]);
+      if (p < end && w_word_prefix(a, p)) since = p;
+    } else {
+      // roll back this word's tokens (linear.cpp:257-262), then [UNK]
+      size_t q = since;
+      while (q < p) {
+        const int32_t t = a.emit[q];
+        a.emit[q] = kNoEmit;
+        q += static_cast<size_t>(a.tok_len[t]);
+      }
+      a.emit[p] = a.unk_id;
+      ++p;
+      while (p < end && !w_word_prefix(a, p)) ++p;
+      since = p;
+    }
+    while (p < end && w_space(a, p)) ++p;
+    if (p >= end || w_anchor(a, p)) return;
+    // after skipped spaces p is a word-prefix position: counter restarts
+    if (w_word_prefix(a, p)) since = p;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a) {
+  const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= a.n_text) return;
+  if (p == 0) {
+    // the reference skips leading whitespace first (linear.cpp:227-229); if the first real
+    // position is not an anchor by itself, this thread owns it
+    size_t q = 0;
+    while (q < a.n_text && w_space(a, q)) ++q;
+    if (q < a.n_text && q != 0 && !w_anchor(a, q)) walk_from(a, q);
+  }
+  if (w_anchor(a, p)) walk_from(a, p);
+}
+
+// ---- compaction of emit[] into the id stream ----------------------------------------------------
+__global__ __launch_bounds__(kBlock) void emit_count_kernel(const int32_t *__restrict__ emit, size_t n,
+                                                            uint32_t *__restrict__ tile_counts) {
+  __shared__ uint32_t sm[8];
+  const size_t base = static_cast<size_t>(blockIdx.x) * kScanTile;
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; j++) {
+    size_t i = base + static_cast<size_t>(j) * kBlock + threadIdx.x;
+    if (i < n && emit[i] != kNoEmit) c++;
+  }
+  uint32_t tot;
+  (void)block_excl_sum(c, sm, tot);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kBlock) void emit_write_kernel(const int32_t *__restrict__ emit, size_t n,
+                                                            const uint32_t *__restrict__ tile_prefix,
+                                                            int32_t *__restrict__ ids) {
+  __shared__ uint32_t sm[8];
+  const size_t base = static_cast<size_t>(blockIdx.x) * kScanTile + static_cast<size_t>(threadIdx.x) * kScanItems;
+  int32_t v[kScanItems];
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; j++) {
+    size_t i = base + j;
+    v[j] = i < n ? emit[i] : kNoEmit;
+    c += v[j] != kNoEmit;
+  }
+  uint32_t tot;
+  size_t o = static_cast<size_t>(block_excl_sum(c, sm, tot)) + tile_prefix[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < kScanItems; j++) {
+    if (v[j] != kNoEmit) ids[o++] = v[j];
+  }
+}
+
+}  // namespace wp
