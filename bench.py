@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — input MB/s tokenized by the HIP Linear WordPiece path on N MI355X GPUs.
+
+A step = one pass of the hot path (UTF-8 decode -> S build -> suffix array + LCP by prefix
+doubling -> scanlines -> greedy walk -> id stream) over one shard per GPU, the shard already
+resident in HBM and the ids left in HBM.  Workload = BASELINE.json configs[1]: a 100 MB
+English-shaped shard with a 29k-line BERT-like vocabulary (synthetic, SURVEY.md §8d config 2;
+enwiki and bert-base-cased vocab.txt are not available offline).  With N > 1 every rank
+tokenizes its own shard (weak scaling, no collective on the data path) and the token ids are
+gathered to rank 0 over RCCL at the end of every step, as the north star prescribes.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import wordpiece_amd as W  # noqa: E402
+from wordpiece_amd import synth  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
+RADIX_BYTES_PER_ELEM = 24  # one radix pass reads and writes a 12-byte (key, index) record
+
+
+class _DevView:
+    """Zero-copy torch view of a device buffer owned by the library."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def _cpu_baseline(text, vocab, target_bytes):
+    """The CPU port (oracle/, OpenMP; SA stage through the reference's own libsais when oracle/_ref
+    was built) timed on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    cut = min(len(text), target_bytes)
+    while cut < len(text) and text[cut] not in b" \n":
+        cut += 1
+    sample = text[:cut]
+    used_ref_sa = O.use_libsais(True)
+    cores = os.cpu_count() or 1
+    try:
+        ov = O.Vocab(vocab)
+        t0 = time.time()
+        ids = ov.encode(sample, threads=cores)
+        dt = time.time() - t0
+    finally:
+        O.use_libsais(False)
+    return {"value": round(len(sample) / 1e6 / dt, 3), "unit": "MB/s", "cores": cores, "kind": "port",
+            "sample": "first %.1f MB of the rank-0 shard, %d ids, %.1f s; oracle/wp_oracle.c with OpenMP, SA stage via %s"
+                      % (len(sample) / 1e6, len(ids), dt,
+                         "the reference's libsais built from source (oracle/_ref)" if used_ref_sa
+                         else "the oracle's own prefix-doubling sorter")}, ids
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mb", type=float, default=100.0, help="shard size per GPU in MB (1 MB = 1e6 bytes)")
+    ap.add_argument("--vocab-size", type=int, default=29000)
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--cpu-sample-mb", type=float, default=32.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--text-file", default=None, help="optional local corpus instead of the synthetic shard")
+    ap.add_argument("--vocab-file", default=None)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload: one shard per rank ----
+    nbytes_target = int(args.mb * 1e6)
+    if args.text_file and args.vocab_file:
+        with open(args.vocab_file, "rb") as f:
+            vocab = f.read().split(b"\n")
+            if vocab and vocab[-1] == b"":
+                vocab.pop()
+        with open(args.text_file, "rb") as f:
+            data = f.read()
+        s, e = W.shard_bounds(data, world)[rank]
+        text = data[s:e][:nbytes_target] if nbytes_target else data[s:e]
+        workload = "local files %s / %s" % (args.text_file, args.vocab_file)
+    else:
+        text, vocab = synth.english_corpus(nbytes_target, seed=args.seed + 1000 * rank, vocab_size=args.vocab_size)
+        workload = ("configs[1]: %.0f MB English-shaped synthetic shard per GPU (SURVEY 8d config 2), "
+                    "%d-line BERT-like vocab" % (args.mb, len(vocab)))
+    nbytes = len(text)
+
+    vocab_h = W.Vocab(vocab, device=local_rank)
+    vocab_h.set_option(W.WP_OPT_STAGE_TIMING, 1)
+    pad = (-nbytes) % 16 + 16
+    d_text = torch.zeros(nbytes + pad, dtype=torch.uint8, device=dev)
+    d_text[:nbytes] = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+
+    gather_buf = None
+
+    def step():
+        d_ids, n_ids = vocab_h.encode_device(d_text.data_ptr(), nbytes)
+        if world > 1:
+            # the only collective: token ids -> rank 0 (counts first, then max-padded gather)
+            cnt = torch.tensor([n_ids], dtype=torch.int64, device=dev)
+            counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(counts, cnt)
+            mx = int(torch.stack(counts).max().item())
+            send = torch.zeros(mx, dtype=torch.int32, device=dev)
+            if n_ids:
+                send[:n_ids] = torch.as_tensor(_DevView(d_ids, n_ids), device=dev)
+            nonlocal gather_buf
+            if rank == 0:
+                gather_buf = [torch.empty(mx, dtype=torch.int32, device=dev) for _ in range(world)]
+            dist.gather(send, gather_buf if rank == 0 else None, dst=0)
+        return n_ids
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    stage_ms = {}
+    radix_ms = radix_elems = radix_launches = 0
+    t0 = time.perf_counter()
+    n_ids = 0
+    for _ in range(args.steps):
+        n_ids = step()
+        st = vocab_h.stats()
+        radix_ms += st["ms_radix_scatter"]
+        radix_elems += st["radix_pass_elems"]
+        radix_launches += st["radix_passes"]
+        for k in ("ms_total", "ms_decode", "ms_sa", "ms_lcp", "ms_scan", "ms_walk"):
+            stage_ms[k] = stage_ms.get(k, 0.0) + st[k]
+    fence()
+    dt = time.perf_counter() - t0
+    st = vocab_h.stats()
+
+    t = torch.tensor([dt, float(nbytes)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, total_bytes = float(tmax[0].item()), float(tsum[1].item())
+    else:
+        dt_max, total_bytes = dt, float(nbytes)
+
+    if rank == 0:
+        ms_per_step = dt_max / args.steps * 1e3
+        value = total_bytes / 1e6 / (dt_max / args.steps)
+        # dominant kernel: the radix scatter pass; algorithmic bytes = 24 B per element moved
+        avg_launch_ms = radix_ms / max(radix_launches, 1)
+        avg_launch_bytes = RADIX_BYTES_PER_ELEM * radix_elems / max(radix_launches, 1)
+        achieved = avg_launch_bytes / 1e9 / (avg_launch_ms / 1e3) if avg_launch_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "radix_scatter_traffic.json")
+        if os.path.exists(tfile):
+            with open(tfile) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "input MB/s tokenized (bert-base-cased vocab)", "value": round(value, 2), "unit": "MB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": workload, "bytes_per_gpu": nbytes, "vocab_lines": len(vocab),
+                       "symbols_n": st["n_total"], "ids_per_step_rank0": int(n_ids), "rounds": st["rounds"],
+                       "sorted_depth": st["sorted_depth"], "symbol_bits": st["symbol_bits"],
+                       "symbols_per_key": st["symbols_per_key"], "active_per_round": st["active_per_round"],
+                       "radix_launches_per_step": radix_launches // max(args.steps, 1),
+                       "id_gather": "rccl gather to rank 0" if world > 1 else "none (single GPU)"},
+            "roofline": {"bound": "hbm", "kernel": "radix_scatter_kernel<uint64>", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 4),
+                         "algorithmic_bytes_per_launch": int(avg_launch_bytes)},
+            "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, cpu_ids = _cpu_baseline(text, vocab, int(args.cpu_sample_mb * 1e6))
+            out["cpu_baseline"] = cb
+            # the sample is a whitespace-cut prefix of the shard: its ids are a prefix of the GPU's
+            d_ids, n = vocab_h.encode_device(d_text.data_ptr(), nbytes)
+            gpu_ids = torch.as_tensor(_DevView(d_ids, n), device=dev)[:len(cpu_ids)].cpu().numpy()
+            out["config"]["ids_match_cpu_port_on_sample"] = bool(np.array_equal(gpu_ids, cpu_ids))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
