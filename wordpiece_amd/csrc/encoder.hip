@@ -253,10 +253,28 @@ static void encode_on_device(wp_vocab *v, const uint8_t *d_text, size_t nbytes, 
   }
 }
 
+// rank[dst[k]] = val[k] for k < m.  Random 4-byte stores run at ~18 G/s on MI355X; partitioning the
+// pairs by the top `bin_bits` of the destination first (radix passes) turns them into stores that
+// stay inside a small window per workgroup, which the L2 merges into full lines.
+static void binned_scatter(uint32_t *dst, uint32_t *val, uint32_t *tmp_dst, uint32_t *tmp_val, size_t m, size_t n,
+                           int bin_bits, uint32_t *out, uint32_t *radix_tmp, hipStream_t st) {
+  if (m == 0) return;
+  const int hb = bit_length(n > 0 ? n - 1 : 0);
+  int cur = 0;
+  if (bin_bits > 0 && hb > 8) {
+    const int lo = std::max(0, hb - bin_bits);
+    cur = radix_sort_pairs<uint32_t>(dst, val, tmp_dst, tmp_val, m, lo, hb, radix_tmp, st, nullptr);
+  }
+  hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kBlock)), dim3(kBlock), 0, st, cur ? tmp_dst : dst,
+                     cur ? tmp_val : val, m, out);
+  WP_LAUNCH_CHECK();
+}
+
 template <typename SymT>
 static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text, size_t n, const uint32_t *d_cps,
                               const uint8_t *d_cls, int bits, size_t *n_ids_out) {
   hipStream_t st = c->stream;
+  static const int bin_bits = getenv("WP_BIN_BITS") ? atoi(getenv("WP_BIN_BITS")) : 0;
   const HostVocab &hv = v->hv;
   wp_stats &S = v->stats;
   const int K = std::max(1, std::min(kMaxK, 64 / bits));
@@ -284,7 +302,10 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
            *d_emit_tmp = nullptr;
   int32_t *d_lcp = nullptr, *d_mid = nullptr, *d_interior = nullptr, *d_rf = nullptr, *d_rb = nullptr;
   RerankAgg *d_agg = nullptr;
-  int2 *d_pool = nullptr;
+  int2 *d_pool = nullptr, *d_gsum_pool = nullptr, *d_gin_pool = nullptr;
+  uint32_t *d_gsum_depth = nullptr, *d_gin_depth = nullptr;
+  int32_t *d_lmin = nullptr, *d_gmin = nullptr;
+  const unsigned sl_groups = cdiv(sl_tiles, kSlGroup);
   for (int pass = 0; pass < 2; pass++) {
     d_sym = ar.take<SymT>(n + 16);
     K0 = ar.take<uint64_t>(n);
@@ -311,6 +332,12 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     d_interior = ar.take<int32_t>(sl_tiles + 1);
     d_depth = ar.take<uint32_t>(4 * static_cast<size_t>(sl_tiles));
     d_pool = ar.take<int2>(4 * static_cast<size_t>(sl_tiles) * D);
+    d_lmin = ar.take<int32_t>(4 * static_cast<size_t>(sl_tiles));
+    d_gsum_pool = ar.take<int2>(4 * static_cast<size_t>(sl_groups) * D);
+    d_gin_pool = ar.take<int2>(4 * static_cast<size_t>(sl_groups) * D);
+    d_gsum_depth = ar.take<uint32_t>(4 * static_cast<size_t>(sl_groups));
+    d_gin_depth = ar.take<uint32_t>(4 * static_cast<size_t>(sl_groups));
+    d_gmin = ar.take<int32_t>(4 * static_cast<size_t>(sl_groups));
     d_emit_cnt = ar.take<uint32_t>(emit_tiles + 1);
     d_emit_tmp = ar.take<uint32_t>(cdiv(emit_tiles, kScanTile) + 8);
     if (pass == 0) ar.commit();
@@ -334,10 +361,13 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     hipLaunchKernelGGL(rerank_agg_kernel, dim3(tiles), dim3(kBlock), 0, st, keys, n, d_agg);
     hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kBlock), 0, st, d_agg, static_cast<size_t>(tiles),
                        c->d_scalars + 4);
+    uint64_t *kother = cur ? K0 : K1;
+    uint32_t *hd = reinterpret_cast<uint32_t *>(kother);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
-                       vals, static_cast<const uint32_t *>(nullptr), n, d_agg, d_sym, n, 0u, K, bits, d_sa, d_rank,
+                       vals, static_cast<const uint32_t *>(nullptr), n, d_agg, d_sym, n, 0u, K, bits, d_sa, hd,
                        d_lcp, slots, other_vals, AG);
     WP_LAUNCH_CHECK();
+    binned_scatter(vals, hd, hd + n, reinterpret_cast<uint32_t *>(keys), n, n, bin_bits, d_rank, d_radix_tmp, st);
   }
   fetch_scalars(c, 6);
   size_t n_act = c->h_scalars[4], n_groups = c->h_scalars[5];
@@ -362,9 +392,12 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     hipLaunchKernelGGL(rerank_agg_kernel, dim3(tiles), dim3(kBlock), 0, st, skeys, n_act, d_agg);
     hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kBlock), 0, st, d_agg, static_cast<size_t>(tiles),
                        c->d_scalars + 4);
+    uint32_t *hd = reinterpret_cast<uint32_t *>(cc ? K0 : K1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
-                       svals, slots, n_act, d_agg, d_sym, n, h, K, bits, d_sa, d_rank, d_lcp, other_slots, nvals, AG);
+                       svals, slots, n_act, d_agg, d_sym, n, h, K, bits, d_sa, hd, d_lcp, other_slots, nvals, AG);
     WP_LAUNCH_CHECK();
+    binned_scatter(svals, hd, hd + n, reinterpret_cast<uint32_t *>(skeys), n_act, n, bin_bits, d_rank, d_radix_tmp,
+                   st);
     fetch_scalars(c, 6);
     n_act = c->h_scalars[4];
     n_groups = c->h_scalars[5];
@@ -407,13 +440,19 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     hipLaunchKernelGGL(sl_summary_kernel, dim3(sl_tiles), dim3(kBlock), 0, st, d_lcp, n, mslot, d_minfo, d_tile_mlo,
                        d_interior, d_rf, d_rb);
     if (carry_lds > 48 * 1024) {
-      WP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sl_carry_kernel),
+      WP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sl_carry_local_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(carry_lds)));
+      WP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sl_carry_group_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(carry_lds)));
     }
-    hipLaunchKernelGGL(sl_carry_kernel, dim3(4), dim3(kWave), carry_lds, st, d_lcp, n, sl_tiles, d_interior,
-                       d_tile_mlo, d_mid, d_minfo, M, D, d_pool, d_depth, c->d_scalars + 8);
+    hipLaunchKernelGGL(sl_carry_local_kernel, dim3(sl_groups, 4), dim3(kWave), carry_lds, st, d_lcp, n, sl_tiles,
+                       d_interior, d_tile_mlo, d_mid, d_minfo, M, D, d_pool, d_depth, d_lmin, sl_groups, d_gsum_pool,
+                       d_gsum_depth, d_gmin, c->d_scalars + 8);
+    hipLaunchKernelGGL(sl_carry_group_kernel, dim3(4), dim3(kWave), carry_lds, st, sl_groups, D, d_gsum_pool,
+                       d_gsum_depth, d_gmin, d_gin_pool, d_gin_depth, c->d_scalars + 8);
     hipLaunchKernelGGL(sl_resolve_kernel, dim3(sl_tiles), dim3(kBlock), 0, st, d_lcp, n, sl_tiles, d_tile_mlo, mslot,
-                       d_mid, d_minfo, d_rf, d_rb, d_pool, d_depth, D, d_bestp, d_bests);
+                       d_mid, d_minfo, d_rf, d_rb, d_pool, d_depth, d_lmin, sl_groups, d_gin_pool, d_gin_depth, D,
+                       d_bestp, d_bests);
     WP_LAUNCH_CHECK();
   }
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[5], st));

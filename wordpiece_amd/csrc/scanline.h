@@ -126,72 +126,94 @@ __global__ __launch_bounds__(kBlock) void sl_summary_kernel(const int32_t *__res
 }
 
 // ---- 2. carry chains ---------------------------------------------------------------------------
-// grid = 4 workgroups of one wave: chain = cls*2 + dir (dir 0: left->right, 1: right->left).
-// pool[(chain*ntiles + tile)*D + q] = q-th entry (len, id) of the stack entering `tile`.
-__global__ __launch_bounds__(kWave) void sl_carry_kernel(const int32_t *__restrict__ lcp, size_t n, unsigned ntiles,
-                                                         const int32_t *__restrict__ interior,
-                                                         const uint32_t *__restrict__ tile_mlo,
-                                                         const int32_t *__restrict__ mid,
-                                                         const uint32_t *__restrict__ minfo, int M, int D,
-                                                         int2 *__restrict__ pool, uint32_t *__restrict__ depth_out,
-                                                         uint32_t *__restrict__ overflow) {
+// chain = cls*2 + dir (dir 0: left->right, 1: right->left).  Two levels, so that the sequential part is
+// short: tiles are grouped by 64.
+//   sl_carry_local : one wave per (group, chain) composes its 64 tiles starting from an EMPTY stack.
+//       For every tile it stores the stack entering the tile *relative to the group start*
+//       (lpool/ldepth) and lmin = the minimum LCP popped since the group start; at the end the
+//       group's summary (gmin, surviving pushes) is stored.
+//   sl_carry_group : one wave per chain walks the groups: stack entering group g+1 =
+//       (stack entering g popped by gmin[g]) ++ summary[g].
+// The stack entering a tile is then  { group stack entries with len <= lmin[tile] } ++ local list,
+// which sl_resolve queries as two levels without materialising it.
+constexpr int kSlGroup = 64;
+
+struct CarryStack {
+  int32_t *slen, *sid;
+  int depth;
+};
+
+// pops: lengths ascend, so the popped entries are a suffix of the stack (ballot over the top 64)
+__device__ __forceinline__ void carry_pop(CarryStack &s, int32_t m, int lane) {
+  while (s.depth > 0) {
+    const int base = max(0, s.depth - kWave);
+    const int q = base + lane;
+    const uint64_t b = __ballot(q < s.depth && s.slen[q] > m);
+    if (!b) break;
+    const int first = __ffsll(static_cast<long long>(b)) - 1;
+    s.depth = base + first;
+    if (first > 0) break;
+  }
+}
+
+__global__ __launch_bounds__(kWave) void sl_carry_local_kernel(
+    const int32_t *__restrict__ lcp, size_t n, unsigned ntiles, const int32_t *__restrict__ interior,
+    const uint32_t *__restrict__ tile_mlo, const int32_t *__restrict__ mid, const uint32_t *__restrict__ minfo,
+    int M, int D, int2 *__restrict__ lpool, uint32_t *__restrict__ ldepth, int32_t *__restrict__ lmin,
+    unsigned ngroups, int2 *__restrict__ gsum_pool, uint32_t *__restrict__ gsum_depth, int32_t *__restrict__ gmin,
+    uint32_t *__restrict__ overflow) {
   extern __shared__ int32_t dyn[];
-  int32_t *slen = dyn, *sid = dyn + D;
+  CarryStack stk{dyn, dyn + D, 0};
   int32_t *win_id = dyn + 2 * D;
   uint32_t *win_info = reinterpret_cast<uint32_t *>(dyn + 2 * D + kCarryWin);
-  const int chain = blockIdx.x, cls = chain >> 1, dir = chain & 1;
+  const unsigned group = blockIdx.x;
+  const int chain = blockIdx.y, cls = chain >> 1, dir = chain & 1;
   const int lane = threadIdx.x;
   const uint64_t lt = (1ull << lane) - 1ull;
-  int depth = 0;
+  const unsigned t_first = group * kSlGroup;
+  const unsigned t_count = min(static_cast<unsigned>(kSlGroup), ntiles - t_first);
   int wlo = 0, whi = 0;  // marks [wlo, whi) are in the LDS window
-  int32_t r_im = 0, r_bnd = 0;
+  // one lane per tile: preload the tile scalars (lane = position in scan order)
+  int32_t r_m = kLcpInf;
   uint32_t r_lo = 0, r_hi = 0;
-  for (unsigned step = 0; step < ntiles; step++) {
-    if ((step & 63u) == 0) {  // preload the scalars of the next 64 tiles, one per lane
-      const unsigned st = step + lane;
-      if (st < ntiles) {
-        const unsigned t = dir ? ntiles - 1 - st : st;
-        const size_t s = static_cast<size_t>(t) * kSlTile;
-        const size_t e = min(n, s + kSlTile);
-        r_im = interior[t];
-        r_bnd = dir ? boundary_lcp(lcp, n, static_cast<long long>(e) - 1)
-                    : boundary_lcp(lcp, n, static_cast<long long>(s) - 1);
-        r_lo = tile_mlo[t];
-        r_hi = tile_mlo[t + 1];
-      }
-    }
-    const unsigned tile = dir ? ntiles - 1 - step : step;
-    const int32_t m = min(__shfl(r_im, step & 63, kWave), __shfl(r_bnd, step & 63, kWave));
-    const int lo = static_cast<int>(__shfl(r_lo, step & 63, kWave));
-    const int hi = static_cast<int>(__shfl(r_hi, step & 63, kWave));
-    // publish the stack entering this tile
+  if (static_cast<unsigned>(lane) < t_count) {
+    const unsigned t = dir ? t_first + t_count - 1 - lane : t_first + lane;
+    const size_t s = static_cast<size_t>(t) * kSlTile;
+    const size_t e = min(n, s + kSlTile);
+    const int32_t bnd = dir ? boundary_lcp(lcp, n, static_cast<long long>(e) - 1)
+                            : boundary_lcp(lcp, n, static_cast<long long>(s) - 1);
+    r_m = min(interior[t], bnd);
+    r_lo = tile_mlo[t];
+    r_hi = tile_mlo[t + 1];
+  }
+  int32_t run_min = kLcpInf;
+  for (unsigned step = 0; step < t_count; step++) {
+    const unsigned tile = dir ? t_first + t_count - 1 - step : t_first + step;
+    const int32_t m = __shfl(r_m, step, kWave);
+    const int lo = static_cast<int>(__shfl(r_lo, step, kWave));
+    const int hi = static_cast<int>(__shfl(r_hi, step, kWave));
+    // publish the (group-relative) stack entering this tile
     const size_t pbase = (static_cast<size_t>(chain) * ntiles + tile) * D;
-    if (lane == 0) depth_out[static_cast<size_t>(chain) * ntiles + tile] = depth;
-    for (int q = lane; q < depth; q += kWave) pool[pbase + q] = make_int2(slen[q], sid[q]);
-    // pops: lengths ascend, so the popped entries are a suffix of the stack
-    while (depth > 0) {
-      const int base = max(0, depth - kWave);
-      const int q = base + lane;
-      const uint64_t b = __ballot(q < depth && slen[q] > m);
-      if (!b) break;
-      const int first = __ffsll(static_cast<long long>(b)) - 1;
-      depth = base + first;
-      if (first > 0) break;
+    if (lane == 0) {
+      ldepth[static_cast<size_t>(chain) * ntiles + tile] = stk.depth;
+      lmin[static_cast<size_t>(chain) * ntiles + tile] = run_min;
     }
+    for (int q = lane; q < stk.depth; q += kWave) lpool[pbase + q] = make_int2(stk.slen[q], stk.sid[q]);
+    carry_pop(stk, m, lane);
+    run_min = min(run_min, m);
     // pushes: this tile's marks of our class that survive to the tile edge, in scan order
     for (int c0 = 0; c0 < hi - lo; c0 += kWave) {
       const int k = c0 + lane;
       const int mm = dir ? hi - 1 - k : lo + k;
       const bool in = k < hi - lo;
-      // slide the window (all lanes agree: the chunk's first mark decides)
-      const int first_mm = dir ? hi - 1 - c0 : lo + c0;
-      const int last_mm = dir ? max(lo, hi - c0 - kWave) : min(hi - 1, lo + c0 + kWave - 1);
-      if (min(first_mm, last_mm) < wlo || max(first_mm, last_mm) >= whi) {
+      const int a = dir ? max(lo, hi - c0 - kWave) : lo + c0;            // lowest mark index of the chunk
+      const int b = dir ? hi - 1 - c0 : min(hi - 1, lo + c0 + kWave - 1);  // highest
+      if (a < wlo || b >= whi) {  // slide the window (uniform decision)
         if (dir) {
-          whi = first_mm + 1;
+          whi = b + 1;
           wlo = max(0, whi - kCarryWin);
         } else {
-          wlo = first_mm;
+          wlo = a;
           whi = min(M, wlo + kCarryWin);
         }
         for (int q = lane; q < whi - wlo; q += kWave) {
@@ -208,20 +230,70 @@ __global__ __launch_bounds__(kWave) void sl_carry_kernel(const int32_t *__restri
       }
       const bool push = in && static_cast<int>(info >> kMarkClsShift) == cls
                         && (info & (dir ? kMarkSurvBwd : kMarkSurvFwd));
-      const uint64_t b = __ballot(push);
-      const int np = __popcll(b);
-      if (depth + np > D) {
+      const uint64_t bm = __ballot(push);
+      const int np = __popcll(bm);
+      if (stk.depth + np > D) {
         if (lane == 0) atomicOr(overflow, 1u);
         break;
       }
       if (push) {
-        const int pos = depth + __popcll(b & lt);
-        slen[pos] = static_cast<int32_t>(info & kMarkLenMask);
-        sid[pos] = id;
+        const int pos = stk.depth + __popcll(bm & lt);
+        stk.slen[pos] = static_cast<int32_t>(info & kMarkLenMask);
+        stk.sid[pos] = id;
       }
-      depth += np;
+      stk.depth += np;
       __builtin_amdgcn_wave_barrier();
     }
+  }
+  // group summary
+  const size_t gi = static_cast<size_t>(chain) * ngroups + group;
+  if (lane == 0) {
+    gsum_depth[gi] = stk.depth;
+    gmin[gi] = run_min;
+  }
+  for (int q = lane; q < stk.depth; q += kWave) gsum_pool[gi * D + q] = make_int2(stk.slen[q], stk.sid[q]);
+}
+
+__global__ __launch_bounds__(kWave) void sl_carry_group_kernel(unsigned ngroups, int D,
+                                                               const int2 *__restrict__ gsum_pool,
+                                                               const uint32_t *__restrict__ gsum_depth,
+                                                               const int32_t *__restrict__ gmin,
+                                                               int2 *__restrict__ gin_pool,
+                                                               uint32_t *__restrict__ gin_depth,
+                                                               uint32_t *__restrict__ overflow) {
+  extern __shared__ int32_t dyn[];
+  CarryStack stk{dyn, dyn + D, 0};
+  const int chain = blockIdx.x, dir = chain & 1;
+  const int lane = threadIdx.x;
+  int32_t r_min = kLcpInf;
+  uint32_t r_depth = 0;
+  for (unsigned step = 0; step < ngroups; step++) {
+    if ((step & 63u) == 0) {
+      const unsigned st = step + lane;
+      if (st < ngroups) {
+        const unsigned g = dir ? ngroups - 1 - st : st;
+        r_min = gmin[static_cast<size_t>(chain) * ngroups + g];
+        r_depth = gsum_depth[static_cast<size_t>(chain) * ngroups + g];
+      }
+    }
+    const unsigned g = dir ? ngroups - 1 - step : step;
+    const size_t gi = static_cast<size_t>(chain) * ngroups + g;
+    const int32_t m = __shfl(r_min, step & 63, kWave);
+    const int add = static_cast<int>(__shfl(r_depth, step & 63, kWave));
+    if (lane == 0) gin_depth[gi] = stk.depth;
+    for (int q = lane; q < stk.depth; q += kWave) gin_pool[gi * D + q] = make_int2(stk.slen[q], stk.sid[q]);
+    carry_pop(stk, m, lane);
+    if (stk.depth + add > D) {
+      if (lane == 0) atomicOr(overflow, 1u);
+      return;
+    }
+    for (int q = lane; q < add; q += kWave) {
+      const int2 e = gsum_pool[gi * D + q];
+      stk.slen[stk.depth + q] = e.x;
+      stk.sid[stk.depth + q] = e.y;
+    }
+    stk.depth += add;
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -257,11 +329,13 @@ __device__ __forceinline__ bool stack_lookup(const StackView &sv, int32_t pm, in
 __global__ __launch_bounds__(kBlock) void sl_resolve_kernel(
     const int32_t *__restrict__ lcp, size_t n, unsigned ntiles, const uint32_t *__restrict__ tile_mlo,
     const uint32_t *__restrict__ mslot, const int32_t *__restrict__ mid, const uint32_t *__restrict__ minfo,
-    const int32_t *__restrict__ reach_fwd, const int32_t *__restrict__ reach_bwd, const int2 *__restrict__ pool,
-    const uint32_t *__restrict__ depth_in, int D, int32_t *__restrict__ best_prefix,
-    int32_t *__restrict__ best_suffix) {
+    const int32_t *__restrict__ reach_fwd, const int32_t *__restrict__ reach_bwd, const int2 *__restrict__ lpool,
+    const uint32_t *__restrict__ ldepth, const int32_t *__restrict__ lmin, unsigned ngroups,
+    const int2 *__restrict__ gin_pool, const uint32_t *__restrict__ gin_depth, int D,
+    int32_t *__restrict__ best_prefix, int32_t *__restrict__ best_suffix) {
   __shared__ int32_t bl[kSlTile + kSlTile / 16 + 2];
-  __shared__ int32_t st_len[4][kStackLds], st_id[4][kStackLds];
+  __shared__ int32_t pml[kSlTile + kSlTile / 16 + 2];
+  __shared__ int32_t st_len[8][kStackLds], st_id[8][kStackLds];  // [chain] local lists, [4+chain] group stacks
   __shared__ uint32_t mk_slot[kMarkLds], mk_info[kMarkLds];
   __shared__ int32_t mk_id[kMarkLds], mk_rf[kMarkLds], mk_rb[kMarkLds];
   __shared__ int32_t wmin[2][8];
@@ -272,15 +346,25 @@ __global__ __launch_bounds__(kBlock) void sl_resolve_kernel(
   for (int q = tid; q <= cnt; q += kBlock) bl[pad16(q)] = boundary_lcp(lcp, n, static_cast<long long>(s) - 1 + q);
   for (int q = cnt + 1 + tid; q <= kSlTile; q += kBlock) bl[pad16(q)] = kLcpInf;
 
-  int depth[4];
+  const unsigned group = blockIdx.x / kSlGroup;
+  int depth[8];
+  int32_t lm[4];
 #pragma unroll
   for (int c = 0; c < 4; c++) {
-    depth[c] = static_cast<int>(depth_in[static_cast<size_t>(c) * ntiles + blockIdx.x]);
-    const size_t pbase = (static_cast<size_t>(c) * ntiles + blockIdx.x) * D;
+    const size_t ti = static_cast<size_t>(c) * ntiles + blockIdx.x;
+    const size_t gi = static_cast<size_t>(c) * ngroups + group;
+    depth[c] = static_cast<int>(ldepth[ti]);
+    depth[4 + c] = static_cast<int>(gin_depth[gi]);
+    lm[c] = lmin[ti];
     for (int q = tid; q < min(depth[c], kStackLds); q += kBlock) {
-      const int2 e = pool[pbase + q];
+      const int2 e = lpool[ti * D + q];
       st_len[c][q] = e.x;
       st_id[c][q] = e.y;
+    }
+    for (int q = tid; q < min(depth[4 + c], kStackLds); q += kBlock) {
+      const int2 e = gin_pool[gi * D + q];
+      st_len[4 + c][q] = e.x;
+      st_id[4 + c][q] = e.y;
     }
   }
   const int mlo = static_cast<int>(tile_mlo[blockIdx.x]), mhi = static_cast<int>(tile_mlo[blockIdx.x + 1]);
@@ -294,7 +378,9 @@ __global__ __launch_bounds__(kBlock) void sl_resolve_kernel(
   }
   __syncthreads();
 
-  // running minima: pml(j) = min bl[0..j], pmr(j) = min bl[j+1..cnt] for this thread's 16 slots
+  // running minima: pml(j) = min bl[0..j], pmr(j) = min bl[j+1..cnt].  Scanned with each thread on 16
+  // consecutive slots (padded LDS index), then stored back so the per-slot phase can run lane-striped
+  // (coalesced stores of the two result arrays).
   const int j0 = tid * kSlItems;
   int32_t cf = kLcpInf, cb = kLcpInf;
 #pragma unroll
@@ -302,50 +388,61 @@ __global__ __launch_bounds__(kBlock) void sl_resolve_kernel(
     cf = min(cf, bl[pad16(j0 + q)]);
     cb = min(cb, bl[pad16(j0 + q + 1)]);
   }
-  // exclusive forward / backward min-scan across the block
   int32_t inf_f = wave_incl_min(cf);
   int32_t ex_f = __shfl_up(inf_f, 1, kWave);
   if (lane == 0) ex_f = kLcpInf;
-  // backward: reverse lanes
-  int32_t rb = __shfl(cb, 63 - lane, kWave);
+  int32_t rb = __shfl(cb, 63 - lane, kWave);  // backward: scan the mirrored lanes
   int32_t inr = wave_incl_min(rb);
   int32_t ex_r = __shfl_up(inr, 1, kWave);
   if (lane == 0) ex_r = kLcpInf;
   int32_t ex_b = __shfl(ex_r, 63 - lane, kWave);
-  if (lane == 63) wmin[0][w] = inf_f;  // wave total forward
-  if (lane == 63) wmin[1][w] = inr;    // wave total (all lanes) backward
+  if (lane == 63) wmin[0][w] = inf_f;  // wave totals
+  if (lane == 63) wmin[1][w] = inr;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < kBlock / kWave; i++) {
     if (i < w) ex_f = min(ex_f, wmin[0][i]);
     if (i > w) ex_b = min(ex_b, wmin[1][i]);
   }
+  {
+    int32_t vf[kSlItems], vb[kSlItems];
+    int32_t run = ex_f;
+#pragma unroll
+    for (int q = 0; q < kSlItems; q++) {
+      run = min(run, bl[pad16(j0 + q)]);
+      vf[q] = run;
+    }
+    run = ex_b;
+#pragma unroll
+    for (int q = kSlItems - 1; q >= 0; q--) {
+      run = min(run, bl[pad16(j0 + q + 1)]);
+      vb[q] = run;
+    }
+    __syncthreads();  // every read of bl[] is done: reuse it for pmr
+#pragma unroll
+    for (int q = 0; q < kSlItems; q++) {
+      pml[pad16(j0 + q)] = vf[q];
+      bl[pad16(j0 + q)] = vb[q];
+    }
+  }
+  __syncthreads();
+  const int32_t *pmr = bl;
 
-  StackView sv[4];
+  StackView sv[8];
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     sv[c].len_lds = st_len[c];
     sv[c].id_lds = st_id[c];
-    sv[c].glob = pool + (static_cast<size_t>(c) * ntiles + blockIdx.x) * D;
+    sv[c].glob = lpool + (static_cast<size_t>(c) * ntiles + blockIdx.x) * D;
     sv[c].depth = depth[c];
+    sv[4 + c].len_lds = st_len[4 + c];
+    sv[4 + c].id_lds = st_id[4 + c];
+    sv[4 + c].glob = gin_pool + (static_cast<size_t>(c) * ngroups + group) * D;
+    sv[4 + c].depth = depth[4 + c];
   }
 
-  // suffix minima inside the thread's chunk for the backward direction
-  int32_t pmr[kSlItems];
-  {
-    int32_t run = ex_b;
-#pragma unroll
-    for (int q = kSlItems - 1; q >= 0; q--) {
-      run = min(run, bl[pad16(j0 + q + 1)]);
-      pmr[q] = run;
-    }
-  }
-  int32_t runf = ex_f;
-#pragma unroll
-  for (int q = 0; q < kSlItems; q++) {
-    const int j = j0 + q;
-    if (j >= cnt) break;
-    runf = min(runf, bl[pad16(j)]);
+  for (int j = tid; j < cnt; j += kBlock) {
+    const int32_t runf = pml[pad16(j)], runb = pmr[pad16(j)];
     const uint32_t slot = static_cast<uint32_t>(s + j);
     int32_t out[2];
     // position among the tile's marks: first mark with slot > `slot`
@@ -376,6 +473,7 @@ __global__ __launch_bounds__(kBlock) void sl_resolve_kernel(
         }
       }
       if (!fx) fx = stack_lookup(sv[cls * 2 + 0], runf, xid, xlen);
+      if (!fx) fx = stack_lookup(sv[4 + cls * 2 + 0], min(runf, lm[cls * 2 + 0]), xid, xlen);
       // right->left scan: nearest mark at or after the slot that still covers it
       int lb = ub;
       if (ub > 0) {
@@ -393,7 +491,8 @@ __global__ __launch_bounds__(kBlock) void sl_resolve_kernel(
           break;
         }
       }
-      if (!fy) fy = stack_lookup(sv[cls * 2 + 1], pmr[q], yid, ylen);
+      if (!fy) fy = stack_lookup(sv[cls * 2 + 1], runb, yid, ylen);
+      if (!fy) fy = stack_lookup(sv[4 + cls * 2 + 1], min(runb, lm[cls * 2 + 1]), yid, ylen);
       // linear.cpp:243-250: both -> x iff strictly longer, else y; one -> that one
       int32_t r = -1;
       if (fx && fy) r = xlen > ylen ? xid : yid;

@@ -44,33 +44,39 @@ __device__ __forceinline__ void rr_flags(const uint64_t *__restrict__ keys, size
   single = flag && (k + 1 == m || keys[k + 1] != me);
 }
 
+// Tile layout for the rerank kernels: wave w of the workgroup owns list entries
+// [tile_base + 512 w, +512), visited in 8 rounds of 64 consecutive entries (lane = entry), so every
+// global access is a fully coalesced wave access and every ordered scan is a ballot + popcount.
+constexpr int kRrRounds = kRrItems;
+constexpr int kRrWaveSpan = kWave * kRrRounds;
+
 __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__restrict__ keys, size_t m,
                                                             RerankAgg *__restrict__ agg) {
-  __shared__ uint32_t sm[8];
-  __shared__ int32_t smx[8];
-  const size_t base = static_cast<size_t>(blockIdx.x) * kRrTile + static_cast<size_t>(threadIdx.x) * kRrItems;
-  int32_t last = -1;
-  uint32_t na = 0, nh = 0;
+  __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
+  const int lane = lane_id(), w = wave_id();
+  const size_t wave_base = static_cast<size_t>(blockIdx.x) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
+  uint32_t na = 0, nh = 0, last = 0;  // last: 1 + list index of the last group head seen, 0 = none
 #pragma unroll
-  for (int j = 0; j < kRrItems; j++) {
-    size_t k = base + j;
-    if (k < m) {
-      bool f, s;
-      rr_flags(keys, m, k, f, s);
-      if (f) last = static_cast<int32_t>(k - static_cast<size_t>(blockIdx.x) * kRrTile);
-      na += !s;
-      nh += (f && !s);
-    }
+  for (int r = 0; r < kRrRounds; r++) {
+    const size_t k = wave_base + static_cast<size_t>(r) * kWave + lane;
+    bool f = false, sg = true;
+    if (k < m) rr_flags(keys, m, k, f, sg);
+    const uint64_t bf = __ballot(f), ba = __ballot(k < m && !sg), bh = __ballot(f && !sg);
+    na += __popcll(ba);
+    nh += __popcll(bh);
+    if (bf) last = static_cast<uint32_t>(wave_base + static_cast<size_t>(r) * kWave + (63 - __clzll(static_cast<long long>(bf))) + 1);
   }
-  uint32_t ta, th;
-  (void)block_excl_sum(na, sm, ta);
-  (void)block_excl_sum(nh, sm, th);
-  int32_t mx = block_incl_max(last, smx);
-  if (threadIdx.x == kBlock - 1) {
+  if (lane == 0) {
+    s_na[w] = na;
+    s_nh[w] = nh;
+    s_last[w] = last;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     RerankAgg a;
-    a.last_flag = mx < 0 ? 0u : static_cast<uint32_t>(static_cast<size_t>(blockIdx.x) * kRrTile + mx + 1);
-    a.n_active = ta;
-    a.n_heads = th;
+    a.n_active = s_na[0] + s_na[1] + s_na[2] + s_na[3];
+    a.n_heads = s_nh[0] + s_nh[1] + s_nh[2] + s_nh[3];
+    a.last_flag = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
     agg[blockIdx.x] = a;
   }
 }
@@ -116,12 +122,39 @@ __global__ __launch_bounds__(kBlock) void rerank_spine_kernel(RerankAgg *__restr
   }
 }
 
+// number of equal symbols at a+t, b+t for t < maxlen (positions >= n never match)
 template <typename SymT>
 __device__ __forceinline__ int32_t lcp_compare(const SymT *__restrict__ sym, size_t n, size_t a, size_t b,
                                                int32_t maxlen) {
+  const size_t hi = a > b ? a : b;
+  if (hi >= n) return 0;
+  const int32_t lim = static_cast<int32_t>(min(static_cast<size_t>(maxlen), n - hi));
   int32_t t = 0;
-  while (t < maxlen && a + t < n && b + t < n && sym[a + t] == sym[b + t]) t++;
+  if (sizeof(SymT) == 1) {
+    // 8 symbols per (unaligned) 64-bit load; the symbol buffer is padded by 16 bytes past n
+    const uint8_t *pa = reinterpret_cast<const uint8_t *>(sym) + a, *pb = reinterpret_cast<const uint8_t *>(sym) + b;
+    while (t < lim) {
+      uint64_t wa, wb;
+      __builtin_memcpy(&wa, pa + t, 8);
+      __builtin_memcpy(&wb, pb + t, 8);
+      const uint64_t x = wa ^ wb;
+      if (x) {
+        t += (__ffsll(static_cast<long long>(x)) - 1) >> 3;
+        break;
+      }
+      t += 8;
+    }
+    return min(t, lim);
+  }
+  while (t < lim && sym[a + t] == sym[b + t]) t++;
   return t;
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_pairs_kernel(const uint32_t *__restrict__ dst,
+                                                               const uint32_t *__restrict__ val, size_t m,
+                                                               uint32_t *__restrict__ out) {
+  size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k < m) out[dst[k]] = val[k];
 }
 
 // Applies one round's split.  ROUND0: list == all slots (slot k == k), keys are packed symbols.
@@ -129,80 +162,83 @@ template <typename SymT, bool ROUND0>
 __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ slots,
     size_t m, const RerankAgg *__restrict__ agg, const SymT *__restrict__ sym, size_t n, uint32_t h, int K,
-    int bits, uint32_t *__restrict__ sa, uint32_t *__restrict__ rank, int32_t *__restrict__ lcp,
+    int bits, uint32_t *__restrict__ sa, uint32_t *__restrict__ hd, int32_t *__restrict__ lcp,
     uint32_t *__restrict__ nslots, uint32_t *__restrict__ nvals, uint32_t *__restrict__ ngid) {
-  __shared__ uint32_t sm[8];
-  __shared__ int32_t smx[8];
-  const size_t tile_base = static_cast<size_t>(blockIdx.x) * kRrTile;
-  const size_t base = tile_base + static_cast<size_t>(threadIdx.x) * kRrItems;
+  __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
+  const int lane = lane_id(), w = wave_id();
+  const size_t wave_base = static_cast<size_t>(blockIdx.x) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
   const RerankAgg pre = agg[blockIdx.x];
+  const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
 
-  bool f[kRrItems], s[kRrItems];
-  uint32_t na = 0, nh = 0;
-  int32_t last = -1;
+  uint64_t bfs[kRrRounds], bas[kRrRounds], bhs[kRrRounds];
+  uint32_t na = 0, nh = 0, last = 0;
 #pragma unroll
-  for (int j = 0; j < kRrItems; j++) {
-    size_t k = base + j;
-    f[j] = false;
-    s[j] = true;
-    if (k < m) {
-      rr_flags(keys, m, k, f[j], s[j]);
-      if (f[j]) last = static_cast<int32_t>(k - tile_base);
-      na += !s[j];
-      nh += (f[j] && !s[j]);
-    }
+  for (int r = 0; r < kRrRounds; r++) {
+    const size_t k = wave_base + static_cast<size_t>(r) * kWave + lane;
+    bool f = false, sg = true;
+    if (k < m) rr_flags(keys, m, k, f, sg);
+    bfs[r] = __ballot(f);
+    bas[r] = __ballot(k < m && !sg);
+    bhs[r] = __ballot(f && !sg);
+    na += __popcll(bas[r]);
+    nh += __popcll(bhs[r]);
+    if (bfs[r]) last = static_cast<uint32_t>(wave_base + static_cast<size_t>(r) * kWave + (63 - __clzll(static_cast<long long>(bfs[r]))) + 1);
   }
-  uint32_t ta, th;
-  uint32_t ea = block_excl_sum(na, sm, ta) + pre.n_active;
-  uint32_t eh = block_excl_sum(nh, sm, th) + pre.n_heads;
-  // head of the group of the entry just before this thread's first entry
-  int32_t inc = block_incl_max(last, smx);
-  __shared__ int32_t shifted[kBlock];
+  if (lane == 0) {
+    s_na[w] = na;
+    s_nh[w] = nh;
+    s_last[w] = last;
+  }
   __syncthreads();
-  shifted[threadIdx.x] = inc;
-  __syncthreads();
-  const int32_t exm = threadIdx.x == 0 ? -1 : shifted[threadIdx.x - 1];
-  // current head as an index into the list (k-space); pre.last_flag is 1-based
-  size_t head = exm >= 0 ? tile_base + exm : (pre.last_flag ? static_cast<size_t>(pre.last_flag) - 1 : 0);
+  uint32_t ea = pre.n_active, eh = pre.n_heads, head1 = pre.last_flag;  // head1: 1-based list index
+  for (int i = 0; i < w; i++) {
+    ea += s_na[i];
+    eh += s_nh[i];
+    head1 = max(head1, s_last[i]);
+  }
 
 #pragma unroll
-  for (int j = 0; j < kRrItems; j++) {
-    size_t k = base + j;
-    if (k >= m) break;
-    if (f[j]) head = k;
-    const uint32_t v = vals[k];
-    const uint32_t x = ROUND0 ? static_cast<uint32_t>(k) : slots[k];
-    const uint32_t head_slot = ROUND0 ? static_cast<uint32_t>(head) : slots[head];
-    sa[x] = v;
-    if (ROUND0) {
-      rank[v] = head_slot;
-      if (k > 0) {
-        int32_t l = -1;
-        if (f[j]) {
-          const uint64_t d = keys[k] ^ keys[k - 1];
-          const int lead = __clzll(static_cast<long long>(d)) - (64 - K * bits);
-          l = lead / bits;
+  for (int r = 0; r < kRrRounds; r++) {
+    const size_t round_base = wave_base + static_cast<size_t>(r) * kWave;
+    const size_t k = round_base + lane;
+    const uint64_t bf = bfs[r], ba = bas[r], bh = bhs[r];
+    if (k < m) {
+      const uint64_t mine = bf & le;
+      const size_t head = mine ? round_base + (63 - __clzll(static_cast<long long>(mine)))
+                               : (head1 ? static_cast<size_t>(head1) - 1 : 0);
+      const bool f = (bf >> lane) & 1ull;
+      const bool act = (ba >> lane) & 1ull;
+      const uint32_t v = vals[k];
+      const uint32_t x = ROUND0 ? static_cast<uint32_t>(k) : slots[k];
+      const uint32_t head_slot = ROUND0 ? static_cast<uint32_t>(head) : slots[head];
+      sa[x] = v;
+      hd[k] = head_slot;  // new rank of suffix v; scattered to rank[v] afterwards
+      if (ROUND0) {
+        if (k > 0) {
+          int32_t l = -1;
+          if (f) {
+            const uint64_t d = keys[k] ^ keys[k - 1];
+            const int lead = __clzll(static_cast<long long>(d)) - (64 - K * bits);
+            l = lead / bits;
+          }
+          lcp[x - 1] = l;
         }
-        lcp[x - 1] = l;
-      }
-    } else {
-      // the rank changes only when the (new) head is not the old group head
-      const bool head_is_new = head > 0 && (keys[head] >> 32) == (keys[head - 1] >> 32);
-      if (head_is_new) rank[v] = head_slot;
-      if (f[j] && k > 0 && (keys[k] >> 32) == (keys[k - 1] >> 32)) {
-        // x-1 is the previous list entry's slot: both belong to one old group
+      } else if (f && k > 0 && (keys[k] >> 32) == (keys[k - 1] >> 32)) {
+        // a new boundary inside an old group: x-1 is the previous list entry's slot
         lcp[x - 1] = static_cast<int32_t>(h)
                      + lcp_compare(sym, n, static_cast<size_t>(vals[k - 1]) + h, static_cast<size_t>(v) + h,
                                    static_cast<int32_t>(h));
       }
+      if (act) {
+        const uint32_t pos = ea + __popcll(ba & lt);
+        nslots[pos] = x;
+        nvals[pos] = v;
+        ngid[pos] = eh + __popcll(bh & le) - 1;
+      }
     }
-    if (!s[j]) {
-      if (f[j]) eh++;
-      nslots[ea] = x;
-      nvals[ea] = v;
-      ngid[ea] = eh - 1;
-      ea++;
-    }
+    ea += __popcll(ba);
+    eh += __popcll(bh);
+    if (bf) head1 = static_cast<uint32_t>(round_base + (63 - __clzll(static_cast<long long>(bf))) + 1);
   }
 }
 
