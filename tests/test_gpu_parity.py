@@ -189,3 +189,30 @@ def test_english_16mb_ids_and_properties():
         a, b = a[keep], b[keep]
         if len(a) == 0:
             break
+
+
+def _oracle_ids_fast(text, vocab):
+    O.use_libsais(True)
+    try:
+        return O.Vocab(vocab).encode(text, threads=os.cpu_count() or 8)
+    finally:
+        O.use_libsais(False)
+
+
+def test_multilingual_32mb_ids():
+    """configs[2]-shaped (mixed en/ru/ja/zh, multibyte, alphabet > 255 -> u32 symbols)."""
+    text, vocab = synth.multilingual_corpus(32_000_000, seed=12, vocab_size=60000)
+    gv = W.Vocab(vocab)
+    ids = gv.encode(text)
+    assert gv.stats()["alphabet"] > 255
+    assert np.array_equal(ids, _oracle_ids_fast(text, vocab))
+
+
+def test_deep_prefix_24mb_ids():
+    """configs[4]-shaped: 512-char words, every stem prefix is a token (stack depth up to 512)."""
+    text, vocab = synth.deep_prefix_corpus(24_000_000, seed=13)
+    gv = W.Vocab(vocab)
+    ids = gv.encode(text)
+    st = gv.stats()
+    assert st["longest_token"] == 512 and st["sorted_depth"] > 512
+    assert np.array_equal(ids, _oracle_ids_fast(text, vocab))

@@ -383,8 +383,9 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
                        d_rank, h, n, K0);
     const int rb = bit_length(n);  // rank+1 <= n
     const int gb = bit_length(n_groups > 0 ? n_groups - 1 : 0);
-    int cc = radix_sort_pairs<uint64_t>(K0, avals, K1, spare_vals, n_act, 0, rb, d_radix_tmp, st, &c->rstats, 0);
-    if (gb > 0) cc = radix_sort_pairs<uint64_t>(K0, avals, K1, spare_vals, n_act, 32, 32 + gb, d_radix_tmp, st, &c->rstats, cc);
+    const BitRange ranges[2] = {{0, rb}, {32, 32 + gb}};
+    const int cc = radix_sort_ranges<uint64_t>(K0, avals, K1, spare_vals, n_act, ranges, gb > 0 ? 2 : 1, d_radix_tmp,
+                                               st, &c->rstats);
     uint64_t *skeys = cc ? K1 : K0;
     uint32_t *svals = cc ? spare_vals : avals;
     uint32_t *nvals = cc ? avals : spare_vals;

@@ -6,6 +6,8 @@
 // written back so that every digit run is a coalesced segment.  HBM traffic per pass and
 // element: sizeof(Key) (histogram) + 2*(sizeof(Key)+4) (scatter).
 #pragma once
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "primitives.h"
@@ -185,33 +187,227 @@ struct RadixStats {
   EventSpans spans;  // around every scatter launch
 };
 
+// ---- single-pass ("onesweep") variant: chained scan with decoupled look-back -------------------
+// One upfront kernel histograms every digit position of the whole sort in a single read of the
+// keys.  Each pass is then ONE kernel: a workgroup takes the next tile number from an atomic
+// ticket (so every lower-numbered tile is already running or done), ranks its tile exactly as
+// above, publishes its 256 digit counts as {flag, count} words and looks back over the
+// predecessors' words until it meets an inclusive prefix.  Words are single 32-bit agent-scope
+// atomics (flag and value travel together, no fence needed); rows are tile-major (1 KiB per tile),
+// so every look-back step is one coalesced wave load.
+constexpr uint32_t kOsFlagLocal = 1u << 30;   // value = this tile's count
+constexpr uint32_t kOsFlagIncl = 2u << 30;    // value = inclusive prefix over tiles 0..t
+constexpr uint32_t kOsValueMask = (1u << 30) - 1u;
+constexpr int kOsMaxPasses = 8;
+
+struct OsPasses {
+  int n;
+  int begin[kOsMaxPasses];
+  uint32_t mask[kOsMaxPasses];
+};
+
+constexpr int kOsHistItems = 16;
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void radix_global_hist_kernel(const KeyT *__restrict__ keys, size_t n,
+                                                                   OsPasses ps, uint32_t *__restrict__ ghist) {
+  __shared__ uint32_t sh[kOsMaxPasses][kRadixBins];
+  for (int p = 0; p < ps.n; p++) sh[p][threadIdx.x] = 0;
+  __syncthreads();
+  const size_t base = static_cast<size_t>(blockIdx.x) * (kBlock * kOsHistItems);
+#pragma unroll 4
+  for (int j = 0; j < kOsHistItems; j++) {
+    const size_t i = base + static_cast<size_t>(j) * kBlock + threadIdx.x;
+    if (i < n) {
+      const KeyT k = keys[i];
+      for (int p = 0; p < ps.n; p++) atomicAdd(&sh[p][static_cast<uint32_t>(k >> ps.begin[p]) & ps.mask[p]], 1u);
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < ps.n; p++) {
+    const uint32_t c = sh[p][threadIdx.x];
+    if (c) atomicAdd(&ghist[p * kRadixBins + threadIdx.x], c);
+  }
+}
+
+// exclusive scan of each pass's 256 bins (one workgroup per pass)
+__global__ __launch_bounds__(kBlock) void radix_digit_base_kernel(uint32_t *__restrict__ ghist) {
+  __shared__ uint32_t sm[8];
+  uint32_t *h = ghist + blockIdx.x * kRadixBins;
+  uint32_t tot;
+  const uint32_t ex = block_excl_sum(h[threadIdx.x], sm, tot);
+  h[threadIdx.x] = ex;
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void radix_onesweep_kernel(
+    const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
+    uint32_t *__restrict__ vout, size_t n, int begin_bit, uint32_t mask, const uint32_t *__restrict__ digit_base,
+    uint32_t *__restrict__ status, uint32_t *__restrict__ ticket) {
+  constexpr int ITEMS = RadixCfg<KeyT>::kItems;
+  constexpr int TILE = RadixCfg<KeyT>::kTile;
+  constexpr int WAVES = kBlock / kWave;
+  __shared__ uint32_t wcnt[WAVES][kRadixBins];
+  __shared__ uint32_t dstart[kRadixBins];
+  __shared__ uint32_t gbase[kRadixBins];
+  __shared__ uint32_t ssum[8];
+  __shared__ uint32_t s_tile;
+  __shared__ KeyT skeys[TILE];
+  __shared__ uint32_t svals[TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+  for (int i = 0; i < WAVES; i++) wcnt[i][tid] = 0;
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const size_t tile_base = static_cast<size_t>(tile) * TILE;
+  const size_t wave_base = tile_base + static_cast<size_t>(w) * (kWave * ITEMS);
+  const uint32_t tile_count = static_cast<uint32_t>(min(static_cast<size_t>(TILE), n - tile_base));
+
+  KeyT key[ITEMS];
+  uint32_t val[ITEMS];
+  uint32_t rnk[ITEMS];
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
+    const bool valid = i < n;
+    key[r] = valid ? kin[i] : static_cast<KeyT>(~static_cast<KeyT>(0));
+    val[r] = valid ? vin[i] : 0u;
+  }
+  volatile uint32_t *mycnt = wcnt[w];
+  const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
+    const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : (kRadixBins - 1);
+    const uint64_t peers = wave_match_any8(d);
+    const int leader = __ffsll(static_cast<long long>(peers)) - 1;
+    uint32_t old = 0;
+    if (lane == leader) {
+      old = mycnt[d];
+      mycnt[d] = old + __popcll(peers);
+    }
+    old = __shfl(old, leader, kWave);
+    rnk[r] = old + __popcll(peers & lt);
+  }
+  __syncthreads();
+  uint32_t tot = 0;
+#pragma unroll
+  for (int i = 0; i < WAVES; i++) {
+    uint32_t c = wcnt[i][tid];
+    wcnt[i][tid] = tot;
+    tot += c;
+  }
+  // the padding slots of the last tile were counted in the top bin: take them out again
+  if (tid == kRadixBins - 1) tot -= (TILE - tile_count);
+  // publish the tile's count for digit `tid`, then look back
+  uint32_t *row = status + static_cast<size_t>(tile) * kRadixBins;
+  __hip_atomic_store(&row[tid], kOsFlagLocal | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t excl = 0;
+  for (long long t = static_cast<long long>(tile) - 1; t >= 0;) {
+    const uint32_t v = __hip_atomic_load(status + static_cast<size_t>(t) * kRadixBins + tid, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t flag = v & ~kOsValueMask;
+    if (flag == 0) {
+      __builtin_amdgcn_s_sleep(1);
+      continue;
+    }
+    excl += v & kOsValueMask;
+    if (flag == kOsFlagIncl) break;
+    t--;
+  }
+  __hip_atomic_store(&row[tid], kOsFlagIncl | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t all;
+  const uint32_t tot_padded = tid == kRadixBins - 1 ? tot + (TILE - tile_count) : tot;
+  uint32_t ds = block_excl_sum(tot_padded, ssum, all);
+  dstart[tid] = ds;
+  gbase[tid] = digit_base[tid] + excl - ds;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
+    const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : (kRadixBins - 1);
+    const uint32_t pos = dstart[d] + wcnt[w][d] + rnk[r];
+    skeys[pos] = key[r];
+    svals[pos] = val[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    const uint32_t k = static_cast<uint32_t>(j) * kBlock + tid;
+    if (k < tile_count) {
+      const KeyT kk = skeys[k];
+      const uint32_t d = static_cast<uint32_t>(kk >> begin_bit) & mask;
+      const size_t o = static_cast<size_t>(gbase[d]) + k;
+      kout[o] = kk;
+      vout[o] = svals[k];
+    }
+  }
+}
+
 template <typename KeyT>
 size_t radix_tmp_words(size_t n) {
   size_t ntiles = cdiv(n, RadixCfg<KeyT>::kTile);
   size_t h = ntiles * kRadixBins;
-  return h + cdiv(h, kScanTile) + 8;
+  return h + cdiv(h, kScanTile) + kOsMaxPasses * kRadixBins + 64;
 }
 
-// Sorts bits [begin_bit, end_bit) of the keys (stable).  Data ping-pongs between (k0,v0) and
-// (k1,v1); returns 0 or 1 = which pair holds the result.  tmp: radix_tmp_words<KeyT>(n) uint32.
+struct BitRange {
+  int begin, end;
+};
+
+inline bool radix_use_onesweep() {
+  static const bool v = !(getenv("WP_RADIX") && std::string(getenv("WP_RADIX")) == "classic");
+  return v;
+}
+
+// Sorts the given bit ranges of the keys, least significant range first (stable LSD).  Data
+// ping-pongs between (k0,v0) and (k1,v1); returns 0 or 1 = which pair holds the result.
+// tmp: radix_tmp_words<KeyT>(n) uint32.
 template <typename KeyT>
-int radix_sort_pairs(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, int begin_bit, int end_bit,
-                     uint32_t *tmp, hipStream_t st, RadixStats *stats, int cur = 0) {
+int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, const BitRange *ranges,
+                      int nranges, uint32_t *tmp, hipStream_t st, RadixStats *stats) {
+  int cur = 0;
   if (n == 0) return cur;
   const unsigned ntiles = cdiv(n, RadixCfg<KeyT>::kTile);
   const size_t h = static_cast<size_t>(ntiles) * kRadixBins;
-  uint32_t *hist = tmp, *scan_tmp = tmp + h;
-  for (int b = begin_bit; b < end_bit; b += kRadixBits) {
-    const int nb = min(kRadixBits, end_bit - b);
-    const uint32_t mask = (1u << nb) - 1u;
+  OsPasses ps;
+  ps.n = 0;
+  for (int r = 0; r < nranges; r++) {
+    for (int b = ranges[r].begin; b < ranges[r].end; b += kRadixBits) {
+      if (ps.n >= kOsMaxPasses) throw std::length_error("too many radix passes");
+      ps.begin[ps.n] = b;
+      ps.mask[ps.n] = (1u << min(kRadixBits, ranges[r].end - b)) - 1u;
+      ps.n++;
+    }
+  }
+  if (ps.n == 0) return cur;
+  const bool onesweep = radix_use_onesweep();
+  uint32_t *status = tmp, *scan_tmp = tmp + h;                  // classic: hist table + scan scratch
+  uint32_t *ghist = tmp + h + cdiv(h, kScanTile) + 8;           // onesweep: [passes][256] digit bases
+  uint32_t *tickets = ghist + kOsMaxPasses * kRadixBins;        // onesweep: one ticket per pass
+  if (onesweep) {
+    WP_HIP(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (kOsMaxPasses * kRadixBins + kOsMaxPasses), st));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_global_hist_kernel<KeyT>), dim3(cdiv(n, kBlock * kOsHistItems)),
+                       dim3(kBlock), 0, st, k0, n, ps, ghist);
+    hipLaunchKernelGGL(radix_digit_base_kernel, dim3(ps.n), dim3(kBlock), 0, st, ghist);
+  }
+  for (int p = 0; p < ps.n; p++) {
     KeyT *ki = cur ? k1 : k0, *ko = cur ? k0 : k1;
     uint32_t *vi = cur ? v1 : v0, *vo = cur ? v0 : v1;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, n, b,
-                       mask, hist, ntiles);
-    device_exclusive_scan(hist, hist, h, scan_tmp, nullptr, st);
-    if (stats) stats->spans.begin(st);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, vi,
-                       ko, vo, n, b, mask, hist, ntiles);
+    if (onesweep) {
+      WP_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t) * h, st));
+      if (stats) stats->spans.begin(st);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, vi, ko,
+                         vo, n, ps.begin[p], ps.mask[p], ghist + p * kRadixBins, status, tickets + p);
+    } else {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, n,
+                         ps.begin[p], ps.mask[p], status, ntiles);
+      device_exclusive_scan(status, status, h, scan_tmp, nullptr, st);
+      if (stats) stats->spans.begin(st);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, vi, ko,
+                         vo, n, ps.begin[p], ps.mask[p], status, ntiles);
+    }
     WP_LAUNCH_CHECK();
     if (stats) {
       stats->spans.end(st);
@@ -221,6 +417,13 @@ int radix_sort_pairs(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, i
     cur ^= 1;
   }
   return cur;
+}
+
+template <typename KeyT>
+int radix_sort_pairs(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, int begin_bit, int end_bit,
+                     uint32_t *tmp, hipStream_t st, RadixStats *stats) {
+  BitRange r{begin_bit, end_bit};
+  return radix_sort_ranges<KeyT>(k0, v0, k1, v1, n, &r, 1, tmp, st, stats);
 }
 
 }  // namespace wp
