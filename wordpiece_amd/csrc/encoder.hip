@@ -465,7 +465,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   if (n_text > 0) {
     WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st));
     WalkArgs wa{d_cls, n_text, d_rank, d_bestp, d_bests, c->d_tok_len, hv.unk_id, d_emit};
-    hipLaunchKernelGGL(walk_kernel, dim3(cdiv(n_text, kBlock)), dim3(kBlock), 0, st, wa);
+    hipLaunchKernelGGL(walk_kernel, dim3(cdiv(cdiv(n_text, kWalkSpan), kBlock)), dim3(kBlock), 0, st, wa);
     const unsigned tiles = cdiv(n_text, kScanTile);
     hipLaunchKernelGGL(emit_count_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt);
     device_exclusive_scan(d_emit_cnt, d_emit_cnt, tiles, d_emit_tmp, c->d_scalars + 9, st);

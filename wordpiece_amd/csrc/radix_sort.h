@@ -19,7 +19,10 @@ constexpr int kRadixBins = 1 << kRadixBits;
 
 template <typename KeyT>
 struct RadixCfg {
-  static constexpr int kItems = sizeof(KeyT) == 8 ? 12 : 16;
+#ifndef WP_RADIX_ITEMS64
+#define WP_RADIX_ITEMS64 20
+#endif
+  static constexpr int kItems = sizeof(KeyT) == 8 ? WP_RADIX_ITEMS64 : 16;
   static constexpr int kTile = kBlock * kItems;
 };
 
@@ -34,11 +37,17 @@ __device__ __forceinline__ uint64_t wave_match_any8(uint32_t digit) {
   return peers;
 }
 
-// hist[digit * ntiles + tile] = number of keys of this tile with that digit
+// Offset table, tile-major: table[tile * 256 + digit].  The histogram kernel fills it with the
+// per-tile digit counts (one coalesced 1 KiB row per workgroup) and adds the row into the sums of
+// its chunk of kColChunk tiles; a single-workgroup spine turns the chunk sums into exclusive
+// prefixes in (digit, tile) order; the apply kernel rewrites every row as global offsets.
+constexpr int kColChunk = 64;
+
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restrict__ keys, size_t n,
                                                             int begin_bit, uint32_t mask,
-                                                            uint32_t *__restrict__ hist, unsigned ntiles) {
+                                                            uint32_t *__restrict__ table,
+                                                            uint32_t *__restrict__ chunk_sums) {
   constexpr int ITEMS = RadixCfg<KeyT>::kItems;
   __shared__ uint32_t sh[kRadixBins];
   sh[threadIdx.x] = 0;
@@ -53,7 +62,64 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
     }
   }
   __syncthreads();
-  hist[static_cast<size_t>(threadIdx.x) * ntiles + blockIdx.x] = sh[threadIdx.x];
+  const uint32_t c = sh[threadIdx.x];
+  table[static_cast<size_t>(blockIdx.x) * kRadixBins + threadIdx.x] = c;
+  if (c) atomicAdd(&chunk_sums[static_cast<size_t>(blockIdx.x / kColChunk) * kRadixBins + threadIdx.x], c);
+}
+
+// single workgroup of 1024 threads = 4 chunk ranges x 256 digits:
+// chunk_pre[chunk][d] = exclusive prefix of chunk_sums in (digit, chunk) order
+constexpr int kSpineParts = 4;
+__global__ __launch_bounds__(kSpineParts * kRadixBins) void radix_spine_kernel(
+    const uint32_t *__restrict__ chunk_sums, uint32_t *__restrict__ chunk_pre, unsigned nchunks) {
+  __shared__ uint32_t part[kSpineParts][kRadixBins];
+  __shared__ uint32_t wtot[4];
+  const int d = threadIdx.x & (kRadixBins - 1), q = threadIdx.x >> 8;
+  const unsigned per = (nchunks + kSpineParts - 1) / kSpineParts;
+  const unsigned c0 = min(nchunks, q * per), c1 = min(nchunks, c0 + per);
+  uint32_t sum = 0;
+  for (unsigned c = c0; c < c1; c++) sum += chunk_sums[static_cast<size_t>(c) * kRadixBins + d];
+  part[q][d] = sum;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < kSpineParts; i++) {
+    const uint32_t v = part[i][d];
+    if (i < q) before += v;
+    total += v;
+  }
+  // exclusive scan of total[d] over the 256 digits (threads 0..255 = waves 0..3 hold q == 0)
+  uint32_t inc = wave_incl_sum(q == 0 ? total : 0u);
+  if (q == 0 && (threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  const int wd = d >> 6;  // wave that owns digit d in the q == 0 row
+  uint32_t base_d = 0;
+  if (q == 0) {
+    for (int i = 0; i < wd; i++) base_d += wtot[i];
+    base_d += inc - total;
+    part[0][d] = base_d;  // every thread has finished reading part[][] (barrier above)
+  }
+  __syncthreads();
+  uint32_t run = part[0][d] + before;
+  for (unsigned c = c0; c < c1; c++) {
+    const size_t i = static_cast<size_t>(c) * kRadixBins + d;
+    chunk_pre[i] = run;
+    run += chunk_sums[i];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void radix_apply_kernel(uint32_t *__restrict__ table,
+                                                             const uint32_t *__restrict__ chunk_sums,
+                                                             unsigned ntiles) {
+  const int d = threadIdx.x;
+  const unsigned t0 = blockIdx.x * kColChunk, t1 = min(ntiles, t0 + kColChunk);
+  uint32_t run = chunk_sums[static_cast<size_t>(blockIdx.x) * kRadixBins + d];
+  for (unsigned t = t0; t < t1; t++) {
+    const size_t i = static_cast<size_t>(t) * kRadixBins + d;
+    const uint32_t v = table[i];
+    table[i] = run;
+    run += v;
+  }
 }
 
 template <typename KeyT>
@@ -120,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
   uint32_t all;
   uint32_t ds = block_excl_sum(tot, ssum, all);
   dstart[tid] = ds;
-  gbase[tid] = goff[static_cast<size_t>(tid) * ntiles + blockIdx.x] - ds;
+  gbase[tid] = goff[static_cast<size_t>(blockIdx.x) * kRadixBins + tid] - ds;
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
@@ -349,7 +415,7 @@ template <typename KeyT>
 size_t radix_tmp_words(size_t n) {
   size_t ntiles = cdiv(n, RadixCfg<KeyT>::kTile);
   size_t h = ntiles * kRadixBins;
-  return h + cdiv(h, kScanTile) + kOsMaxPasses * kRadixBins + 64;
+  return h + 2 * (cdiv(ntiles, kColChunk) + 1) * kRadixBins + kOsMaxPasses * kRadixBins + 64;
 }
 
 struct BitRange {
@@ -357,7 +423,9 @@ struct BitRange {
 };
 
 inline bool radix_use_onesweep() {
-  static const bool v = !(getenv("WP_RADIX") && std::string(getenv("WP_RADIX")) == "classic");
+  // measured on MI355X: the chained look-back costs more than the separate histogram pass (every
+  // look-back step is a cross-XCD miss), so the two-kernel pass is the default
+  static const bool v = getenv("WP_RADIX") && std::string(getenv("WP_RADIX")) == "onesweep";
   return v;
 }
 
@@ -383,8 +451,10 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
   }
   if (ps.n == 0) return cur;
   const bool onesweep = radix_use_onesweep();
-  uint32_t *status = tmp, *scan_tmp = tmp + h;                  // classic: hist table + scan scratch
-  uint32_t *ghist = tmp + h + cdiv(h, kScanTile) + 8;           // onesweep: [passes][256] digit bases
+  const unsigned nchunks = cdiv(ntiles, kColChunk);
+  uint32_t *status = tmp, *chunk_sums = tmp + h;                // classic: offset table + chunk sums
+  uint32_t *chunk_pre = chunk_sums + static_cast<size_t>(nchunks + 1) * kRadixBins;
+  uint32_t *ghist = chunk_pre + static_cast<size_t>(nchunks + 1) * kRadixBins;  // onesweep: digit bases
   uint32_t *tickets = ghist + kOsMaxPasses * kRadixBins;        // onesweep: one ticket per pass
   if (onesweep) {
     WP_HIP(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (kOsMaxPasses * kRadixBins + kOsMaxPasses), st));
@@ -401,9 +471,12 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, vi, ko,
                          vo, n, ps.begin[p], ps.mask[p], ghist + p * kRadixBins, status, tickets + p);
     } else {
+      WP_HIP(hipMemsetAsync(chunk_sums, 0, sizeof(uint32_t) * static_cast<size_t>(nchunks) * kRadixBins, st));
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, n,
-                         ps.begin[p], ps.mask[p], status, ntiles);
-      device_exclusive_scan(status, status, h, scan_tmp, nullptr, st);
+                         ps.begin[p], ps.mask[p], status, chunk_sums);
+      hipLaunchKernelGGL(radix_spine_kernel, dim3(1), dim3(kSpineParts * kRadixBins), 0, st, chunk_sums, chunk_pre,
+                         nchunks);
+      hipLaunchKernelGGL(radix_apply_kernel, dim3(nchunks), dim3(kBlock), 0, st, status, chunk_pre, ntiles);
       if (stats) stats->spans.begin(st);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, vi, ko,
                          vo, n, ps.begin[p], ps.mask[p], status, ntiles);

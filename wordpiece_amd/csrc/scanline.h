@@ -336,6 +336,8 @@ __global__ __launch_bounds__(kBlock) void sl_resolve_kernel(
   __shared__ int32_t bl[kSlTile + kSlTile / 16 + 2];
   __shared__ int32_t pml[kSlTile + kSlTile / 16 + 2];
   __shared__ int32_t st_len[8][kStackLds], st_id[8][kStackLds];  // [chain] local lists, [4+chain] group stacks
+  __shared__ int32_t mg_len[4][kStackLds], mg_id[4][kStackLds];  // merged stack entering the tile, per chain
+  __shared__ int mg_depth[4];                                    // -1: too deep for LDS, use the two-level lookup
   __shared__ uint32_t mk_slot[kMarkLds], mk_info[kMarkLds];
   __shared__ int32_t mk_id[kMarkLds], mk_rf[kMarkLds], mk_rb[kMarkLds];
   __shared__ int32_t wmin[2][8];
@@ -375,6 +377,30 @@ __global__ __launch_bounds__(kBlock) void sl_resolve_kernel(
     mk_id[q] = mid[mlo + q];
     mk_rf[q] = reach_fwd[mlo + q];
     mk_rb[q] = reach_bwd[mlo + q];
+  }
+  __syncthreads();
+
+  // merged stack per chain: { group entries with len <= lmin } ++ local list (all ascending in len)
+  if (tid < 4) {
+    const int c = tid;
+    int ng = 0;
+    const int dg = depth[4 + c], dl = depth[c];
+    int md = -1;
+    if (dg <= kStackLds && dl <= kStackLds) {
+      while (ng < dg && st_len[4 + c][ng] <= lm[c]) ng++;
+      if (ng + dl <= kStackLds) {
+        for (int q = 0; q < ng; q++) {
+          mg_len[c][q] = st_len[4 + c][q];
+          mg_id[c][q] = st_id[4 + c][q];
+        }
+        for (int q = 0; q < dl; q++) {
+          mg_len[c][ng + q] = st_len[c][q];
+          mg_id[c][ng + q] = st_id[c][q];
+        }
+        md = ng + dl;
+      }
+    }
+    mg_depth[c] = md;
   }
   __syncthreads();
 
@@ -472,8 +498,22 @@ __global__ __launch_bounds__(kBlock) void sl_resolve_kernel(
           break;
         }
       }
-      if (!fx) fx = stack_lookup(sv[cls * 2 + 0], runf, xid, xlen);
-      if (!fx) fx = stack_lookup(sv[4 + cls * 2 + 0], min(runf, lm[cls * 2 + 0]), xid, xlen);
+      if (!fx) {
+        const int c = cls * 2 + 0, md = mg_depth[c];
+        if (md >= 0) {
+          for (int q2 = md - 1; q2 >= 0; q2--) {
+            if (mg_len[c][q2] <= runf) {
+              xid = mg_id[c][q2];
+              xlen = mg_len[c][q2];
+              fx = true;
+              break;
+            }
+          }
+        } else {
+          fx = stack_lookup(sv[c], runf, xid, xlen);
+          if (!fx) fx = stack_lookup(sv[4 + c], min(runf, lm[c]), xid, xlen);
+        }
+      }
       // right->left scan: nearest mark at or after the slot that still covers it
       int lb = ub;
       if (ub > 0) {
@@ -491,8 +531,22 @@ __global__ __launch_bounds__(kBlock) void sl_resolve_kernel(
           break;
         }
       }
-      if (!fy) fy = stack_lookup(sv[cls * 2 + 1], runb, yid, ylen);
-      if (!fy) fy = stack_lookup(sv[4 + cls * 2 + 1], min(runb, lm[cls * 2 + 1]), yid, ylen);
+      if (!fy) {
+        const int c = cls * 2 + 1, md = mg_depth[c];
+        if (md >= 0) {
+          for (int q2 = md - 1; q2 >= 0; q2--) {
+            if (mg_len[c][q2] <= runb) {
+              yid = mg_id[c][q2];
+              ylen = mg_len[c][q2];
+              fy = true;
+              break;
+            }
+          }
+        } else {
+          fy = stack_lookup(sv[c], runb, yid, ylen);
+          if (!fy) fy = stack_lookup(sv[4 + c], min(runb, lm[c]), yid, ylen);
+        }
+      }
       // linear.cpp:243-250: both -> x iff strictly longer, else y; one -> that one
       int32_t r = -1;
       if (fx && fy) r = xlen > ylen ? xid : yid;

@@ -154,7 +154,10 @@ __global__ __launch_bounds__(kBlock) void scatter_pairs_kernel(const uint32_t *_
                                                                const uint32_t *__restrict__ val, size_t m,
                                                                uint32_t *__restrict__ out) {
   size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (k < m) out[dst[k]] = val[k];
+  if (k < m) {
+    const uint32_t v = val[k];
+    if (v != 0xffffffffu) out[dst[k]] = v;  // 0xffffffff = rank unchanged this round
+  }
 }
 
 // Applies one round's split.  ROUND0: list == all slots (slot k == k), keys are packed symbols.
@@ -212,7 +215,11 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
       const uint32_t x = ROUND0 ? static_cast<uint32_t>(k) : slots[k];
       const uint32_t head_slot = ROUND0 ? static_cast<uint32_t>(head) : slots[head];
       sa[x] = v;
-      hd[k] = head_slot;  // new rank of suffix v; scattered to rank[v] afterwards
+      // new rank of suffix v, scattered to rank[v] afterwards; in rounds >= 1 the first subgroup of
+      // an old group keeps its rank (its head is the old head): marked "unchanged"
+      bool changed = true;
+      if (!ROUND0) changed = head > 0 && (keys[head] >> 32) == (keys[head - 1] >> 32);
+      hd[k] = changed ? head_slot : 0xffffffffu;
       if (ROUND0) {
         if (k > 0) {
           int32_t l = -1;

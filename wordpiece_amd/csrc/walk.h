@@ -67,17 +67,28 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
   }
 }
 
+// Each thread owns kWalkSpan consecutive positions and walks from every anchor among them (about one
+// position in five is an anchor, so a thread-per-position launch would leave most lanes idle while
+// the few active ones wait on their dependent gathers).
+constexpr int kWalkSpan = 8;
 __global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a) {
-  const size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (p >= a.n_text) return;
-  if (p == 0) {
+  const size_t p0 = (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) * kWalkSpan;
+  if (p0 >= a.n_text) return;
+  if (p0 == 0) {
     // the reference skips leading whitespace first (linear.cpp:227-229); if the first real
     // position is not an anchor by itself, this thread owns it
     size_t q = 0;
     while (q < a.n_text && w_space(a, q)) ++q;
     if (q < a.n_text && q != 0 && !w_anchor(a, q)) walk_from(a, q);
   }
-  if (w_anchor(a, p)) walk_from(a, p);
+  const size_t p1 = min(a.n_text, p0 + kWalkSpan);
+  uint8_t prev = p0 > 0 ? a.cls[p0 - 1] : 0;
+  for (size_t p = p0; p < p1; p++) {
+    const uint8_t c = a.cls[p];
+    const bool anchor = !(c & kClsSpace) && (p == 0 || w_hard(c) || w_hard(prev));
+    prev = c;
+    if (anchor) walk_from(a, p);
+  }
 }
 
 // ---- compaction of emit[] into the id stream ----------------------------------------------------
