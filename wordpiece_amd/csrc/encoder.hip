@@ -16,6 +16,7 @@
 
 #include "../../include/wordpiece_amd.h"
 #include "decode.h"
+#include "local_sort.h"
 #include "radix_sort.h"
 #include "scanline.h"
 #include "suffix_array.h"
@@ -253,28 +254,10 @@ static void encode_on_device(wp_vocab *v, const uint8_t *d_text, size_t nbytes, 
   }
 }
 
-// rank[dst[k]] = val[k] for k < m.  Random 4-byte stores run at ~18 G/s on MI355X; partitioning the
-// pairs by the top `bin_bits` of the destination first (radix passes) turns them into stores that
-// stay inside a small window per workgroup, which the L2 merges into full lines.
-static void binned_scatter(uint32_t *dst, uint32_t *val, uint32_t *tmp_dst, uint32_t *tmp_val, size_t m, size_t n,
-                           int bin_bits, uint32_t *out, uint32_t *radix_tmp, hipStream_t st) {
-  if (m == 0) return;
-  const int hb = bit_length(n > 0 ? n - 1 : 0);
-  int cur = 0;
-  if (bin_bits > 0 && hb > 8) {
-    const int lo = std::max(0, hb - bin_bits);
-    cur = radix_sort_pairs<uint32_t>(dst, val, tmp_dst, tmp_val, m, lo, hb, radix_tmp, st, nullptr);
-  }
-  hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kBlock)), dim3(kBlock), 0, st, cur ? tmp_dst : dst,
-                     cur ? tmp_val : val, m, out);
-  WP_LAUNCH_CHECK();
-}
-
 template <typename SymT>
 static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text, size_t n, const uint32_t *d_cps,
                               const uint8_t *d_cls, int bits, size_t *n_ids_out) {
   hipStream_t st = c->stream;
-  static const int bin_bits = getenv("WP_BIN_BITS") ? atoi(getenv("WP_BIN_BITS")) : 0;
   const HostVocab &hv = v->hv;
   wp_stats &S = v->stats;
   const int K = std::max(1, std::min(kMaxK, 64 / bits));
@@ -302,6 +285,9 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
            *d_emit_tmp = nullptr;
   int32_t *d_lcp = nullptr, *d_mid = nullptr, *d_interior = nullptr, *d_rf = nullptr, *d_rb = nullptr;
   RerankAgg *d_agg = nullptr;
+  uint32_t *d_ghead = nullptr, *d_large_id = nullptr, *d_large_off = nullptr, *d_gscan_tmp = nullptr, *LV0 = nullptr,
+           *LV1 = nullptr, *LPOS = nullptr;
+  uint64_t *LK1 = nullptr;
   int2 *d_pool = nullptr, *d_gsum_pool = nullptr, *d_gin_pool = nullptr;
   uint32_t *d_gsum_depth = nullptr, *d_gin_depth = nullptr;
   int32_t *d_lmin = nullptr, *d_gmin = nullptr;
@@ -319,6 +305,14 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     d_rank = ar.take<uint32_t>(n);
     d_lcp = ar.take<int32_t>(n);
     d_radix_tmp = ar.take<uint32_t>(radix_words);
+    d_ghead = ar.take<uint32_t>(n / 2 + 4);
+    d_large_id = ar.take<uint32_t>(n / 2 + 4);
+    d_large_off = ar.take<uint32_t>(n / 2 + 4);
+    d_gscan_tmp = ar.take<uint32_t>(cdiv(n / 2 + 4, kScanTile) + 8);
+    LK1 = ar.take<uint64_t>(n);
+    LV0 = ar.take<uint32_t>(n);
+    LV1 = ar.take<uint32_t>(n);
+    LPOS = ar.take<uint32_t>(n);
     d_agg = ar.take<RerankAgg>(rr_tiles + 1);
     d_mslot0 = ar.take<uint32_t>(M + 1);
     d_mslot1 = ar.take<uint32_t>(M + 1);
@@ -352,6 +346,15 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[2], st));
 
   // ---------------- suffix array by prefix doubling ----------------
+  static const bool use_local = !(getenv("WP_LOCAL_SORT") && atoi(getenv("WP_LOCAL_SORT")) == 0);
+  // after every rerank: classify the new groups (large ones take the global path next round)
+  auto classify_groups = [&](size_t list_len) {
+    const size_t cap = list_len / 2 + 1;  // a group has >= 2 entries
+    hipLaunchKernelGGL(group_classify_kernel, dim3(cdiv(cap, kBlock)), dim3(kBlock), 0, st, d_ghead,
+                       c->d_scalars + 5, d_large_id, d_large_off, cap);
+    device_exclusive_scan(d_large_id, d_large_id, cap, d_gscan_tmp, c->d_scalars + 6, st, c->d_scalars + 5);
+    device_exclusive_scan(d_large_off, d_large_off, cap, d_gscan_tmp, c->d_scalars + 7, st, c->d_scalars + 5);
+  };
   int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, K * bits, d_radix_tmp, st, &c->rstats);
   uint64_t *keys = cur ? K1 : K0;
   uint32_t *vals = cur ? V1 : V0, *other_vals = cur ? V0 : V1;
@@ -360,17 +363,19 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     const unsigned tiles = cdiv(n, kRrTile);
     hipLaunchKernelGGL(rerank_agg_kernel, dim3(tiles), dim3(kBlock), 0, st, keys, n, d_agg);
     hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kBlock), 0, st, d_agg, static_cast<size_t>(tiles),
-                       c->d_scalars + 4);
+                       c->d_scalars + 4, d_ghead);
     uint64_t *kother = cur ? K0 : K1;
     uint32_t *hd = reinterpret_cast<uint32_t *>(kother);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
                        vals, static_cast<const uint32_t *>(nullptr), n, d_agg, d_sym, n, 0u, K, bits, d_sa, hd,
-                       d_lcp, slots, other_vals, AG);
+                       d_lcp, slots, other_vals, AG, d_ghead);
+    hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, vals, hd, n, d_rank);
     WP_LAUNCH_CHECK();
-    binned_scatter(vals, hd, hd + n, reinterpret_cast<uint32_t *>(keys), n, n, bin_bits, d_rank, d_radix_tmp, st);
+    if (use_local) classify_groups(n);
   }
-  fetch_scalars(c, 6);
+  fetch_scalars(c, 8);
   size_t n_act = c->h_scalars[4], n_groups = c->h_scalars[5];
+  size_t n_large_groups = use_local ? c->h_scalars[6] : 0, n_large = use_local ? c->h_scalars[7] : 0;
   uint64_t depth = static_cast<uint64_t>(K);
   int rounds = 1;
   S.active_per_round[0] = static_cast<int64_t>(n);
@@ -379,29 +384,57 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   while (n_act > 0 && (full || depth < need_depth)) {
     if (rounds < 40) S.active_per_round[rounds] = static_cast<int64_t>(n_act);
     const uint32_t h = static_cast<uint32_t>(std::min<uint64_t>(depth, 0x7fffffffu));
-    hipLaunchKernelGGL(build_keys_round_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, avals, AG, n_act,
-                       d_rank, h, n, K0);
     const int rb = bit_length(n);  // rank+1 <= n
-    const int gb = bit_length(n_groups > 0 ? n_groups - 1 : 0);
-    const BitRange ranges[2] = {{0, rb}, {32, 32 + gb}};
-    const int cc = radix_sort_ranges<uint64_t>(K0, avals, K1, spare_vals, n_act, ranges, gb > 0 ? 2 : 1, d_radix_tmp,
-                                               st, &c->rstats);
-    uint64_t *skeys = cc ? K1 : K0;
-    uint32_t *svals = cc ? spare_vals : avals;
-    uint32_t *nvals = cc ? avals : spare_vals;
+    uint64_t *skeys, *kfree;
+    uint32_t *svals, *nvals;
+    if (use_local) {
+      // small groups: one LDS-resident segmented sort per window of the list
+      skeys = K0;
+      kfree = K1;
+      svals = spare_vals;
+      nvals = avals;  // free again once the sorts have consumed it
+      hipLaunchKernelGGL(local_sort_kernel, dim3(cdiv(n_act, kLsT)), dim3(kBlock), 0, st, avals, AG, n_act, d_ghead,
+                         static_cast<uint32_t>(n_groups), d_rank, h, n, rb, skeys, svals);
+      if (n_large > 0) {  // large groups: extract, global radix sort on (dense large id, rank[i+h]), write back
+        hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, avals, AG, n_act,
+                           d_ghead, d_large_id, d_large_off, d_rank, h, n, K1, LV0, LPOS);
+        const int lgb = bit_length(n_large_groups > 0 ? n_large_groups - 1 : 0);
+        const BitRange ranges[2] = {{0, rb}, {32, 32 + lgb}};
+        const int lc = radix_sort_ranges<uint64_t>(K1, LV0, LK1, LV1, n_large, ranges, lgb > 0 ? 2 : 1, d_radix_tmp,
+                                                   st, &c->rstats);
+        hipLaunchKernelGGL(large_writeback_kernel, dim3(cdiv(n_large, kBlock)), dim3(kBlock), 0, st,
+                           lc ? LK1 : K1, lc ? LV1 : LV0, LPOS, n_large, AG, skeys, svals);
+      }
+      WP_LAUNCH_CHECK();
+    } else {
+      hipLaunchKernelGGL(build_keys_round_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, avals, AG, n_act,
+                         d_rank, h, n, K0);
+      const int gb = bit_length(n_groups > 0 ? n_groups - 1 : 0);
+      const BitRange ranges[2] = {{0, rb}, {32, 32 + gb}};
+      const int cc = radix_sort_ranges<uint64_t>(K0, avals, K1, spare_vals, n_act, ranges, gb > 0 ? 2 : 1,
+                                                 d_radix_tmp, st, &c->rstats);
+      skeys = cc ? K1 : K0;
+      kfree = cc ? K0 : K1;
+      svals = cc ? spare_vals : avals;
+      nvals = cc ? avals : spare_vals;
+    }
     const unsigned tiles = cdiv(n_act, kRrTile);
     hipLaunchKernelGGL(rerank_agg_kernel, dim3(tiles), dim3(kBlock), 0, st, skeys, n_act, d_agg);
     hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kBlock), 0, st, d_agg, static_cast<size_t>(tiles),
-                       c->d_scalars + 4);
-    uint32_t *hd = reinterpret_cast<uint32_t *>(cc ? K0 : K1);
+                       c->d_scalars + 4, d_ghead);
+    uint32_t *hd = reinterpret_cast<uint32_t *>(kfree);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
-                       svals, slots, n_act, d_agg, d_sym, n, h, K, bits, d_sa, hd, d_lcp, other_slots, nvals, AG);
+                       svals, slots, n_act, d_agg, d_sym, n, h, K, bits, d_sa, hd, d_lcp, other_slots, nvals, AG,
+                       d_ghead);
+    hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, svals, hd, n_act,
+                       d_rank);
     WP_LAUNCH_CHECK();
-    binned_scatter(svals, hd, hd + n, reinterpret_cast<uint32_t *>(skeys), n_act, n, bin_bits, d_rank, d_radix_tmp,
-                   st);
-    fetch_scalars(c, 6);
+    if (use_local) classify_groups(n_act);
+    fetch_scalars(c, 8);
     n_act = c->h_scalars[4];
     n_groups = c->h_scalars[5];
+    n_large_groups = use_local ? c->h_scalars[6] : 0;
+    n_large = use_local ? c->h_scalars[7] : 0;
     std::swap(slots, other_slots);
     avals = nvals;
     spare_vals = svals;

@@ -1,0 +1,219 @@
+// local_sort.h — segmented sort of the active list for prefix-doubling rounds r >= 1.
+//
+// In round r every still-tied group (contiguous in the active list) must be sorted by
+// rank[i+h].  Most groups are small (after 9 symbols of English text 79 % of the active
+// entries sit in groups of <= 2048), so a workgroup takes a window of whole groups into LDS,
+// gathers their second keys and sorts the window there with 10-bit LSD passes on the composite
+// (local group number, rank[i+h]+1): no HBM pass per digit, one read and one write per entry.
+// Only groups larger than kLsMaxGroup take the global radix path (extract -> sort -> write back).
+//
+// Window rule: workgroup t owns the groups whose head lies in list range [t*T, (t+1)*T).  With
+// kLsMaxGroup >= T at most the last owned group can be "large", so a window holds < T + kLsMaxGroup
+// entries.
+#pragma once
+#include "primitives.h"
+
+namespace wp {
+
+constexpr int kLsT = 2048;                // nominal list entries per workgroup
+constexpr int kLsMaxGroup = 2048;         // groups above this size use the global path
+constexpr int kLsCap = kLsT + kLsMaxGroup;  // LDS capacity in entries
+constexpr int kLsItems = kLsCap / kBlock;   // 16
+constexpr int kLsBits = 10;
+constexpr int kLsBins = 1 << kLsBits;
+constexpr int kLsGroupBits = 12;  // local group number < kLsCap
+
+__device__ __forceinline__ uint64_t wave_match_any_bits(uint32_t digit, int nbits) {
+  uint64_t peers = ~0ull;
+  for (int b = 0; b < nbits; b++) {
+    const bool bit = (digit >> b) & 1u;
+    const uint64_t m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+// group g is [ghead[g], ghead[g+1]); large[g] = size > kLsMaxGroup; the exclusive scans of
+// large[] (dense number of the large group) and of the large sizes (offset in the large list)
+// are produced by device_exclusive_scan on the two arrays written here.
+__global__ __launch_bounds__(kBlock) void group_classify_kernel(const uint32_t *__restrict__ ghead,
+                                                                const uint32_t *__restrict__ n_groups_dev,
+                                                                uint32_t *__restrict__ large_flag,
+                                                                uint32_t *__restrict__ large_size, size_t cap) {
+  const size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (g >= cap) return;
+  uint32_t f = 0, sz = 0;
+  if (g < *n_groups_dev) {
+    const uint32_t s = ghead[g + 1] - ghead[g];
+    if (s > kLsMaxGroup) {
+      f = 1;
+      sz = s;
+    }
+  }
+  large_flag[g] = f;
+  large_size[g] = sz;
+}
+
+// entries of large groups -> (key, val, list position) in the large list
+__global__ __launch_bounds__(kBlock) void large_extract_kernel(
+    const uint32_t *__restrict__ aval, const uint32_t *__restrict__ agid, size_t m,
+    const uint32_t *__restrict__ ghead, const uint32_t *__restrict__ large_id,
+    const uint32_t *__restrict__ large_off, const uint32_t *__restrict__ rank, uint32_t h, size_t n,
+    uint64_t *__restrict__ lkey, uint32_t *__restrict__ lval, uint32_t *__restrict__ lpos) {
+  const size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k >= m) return;
+  const uint32_t g = agid[k];
+  const uint32_t h0 = ghead[g];
+  if (ghead[g + 1] - h0 <= kLsMaxGroup) return;
+  const uint32_t j = large_off[g] + (static_cast<uint32_t>(k) - h0);
+  const uint32_t v = aval[k];
+  const size_t t = static_cast<size_t>(v) + h;
+  const uint32_t r2 = t < n ? rank[t] + 1u : 0u;
+  lkey[j] = (static_cast<uint64_t>(large_id[g]) << 32) | r2;
+  lval[j] = v;
+  lpos[j] = static_cast<uint32_t>(k);
+}
+
+// sorted large list -> back to the list positions, with the original group id in the high word
+__global__ __launch_bounds__(kBlock) void large_writeback_kernel(const uint64_t *__restrict__ lkey,
+                                                                 const uint32_t *__restrict__ lval,
+                                                                 const uint32_t *__restrict__ lpos, size_t nl,
+                                                                 const uint32_t *__restrict__ agid,
+                                                                 uint64_t *__restrict__ kout,
+                                                                 uint32_t *__restrict__ vout) {
+  const size_t j = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (j >= nl) return;
+  const uint32_t k = lpos[j];
+  kout[k] = (static_cast<uint64_t>(agid[k]) << 32) | (lkey[j] & 0xffffffffull);
+  vout[k] = lval[j];
+}
+
+__global__ __launch_bounds__(kBlock) void local_sort_kernel(const uint32_t *__restrict__ aval,
+                                                            const uint32_t *__restrict__ agid, size_t m,
+                                                            const uint32_t *__restrict__ ghead, uint32_t n_groups,
+                                                            const uint32_t *__restrict__ rank, uint32_t h, size_t n,
+                                                            int rbits, uint64_t *__restrict__ kout,
+                                                            uint32_t *__restrict__ vout) {
+  constexpr int WAVES = kBlock / kWave;
+  __shared__ uint64_t skey[kLsCap];
+  __shared__ uint32_t sval[kLsCap];
+  __shared__ uint32_t wc[WAVES][kLsBins];
+  __shared__ uint32_t ssum[8];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t lo = static_cast<size_t>(blockIdx.x) * kLsT;
+  const size_t hi = min(m, lo + kLsT);
+  // owned groups [g_first, g_end)
+  const uint32_t g0 = agid[lo];
+  const uint32_t g_first = ghead[g0] == lo ? g0 : g0 + 1;
+  uint32_t g_end = n_groups;
+  if (hi < m) {
+    const uint32_t g1 = agid[hi];
+    g_end = ghead[g1] == hi ? g1 : g1 + 1;
+  }
+  if (g_first >= g_end) return;
+  const uint32_t a = ghead[g_first];
+  uint32_t b = ghead[g_end];
+  if (b - ghead[g_end - 1] > kLsMaxGroup) b = ghead[g_end - 1];  // the last owned group is large
+  const uint32_t cnt = b - a;
+  if (cnt == 0) return;
+
+  // wave w owns window entries [w*WSPAN, (w+1)*WSPAN) in nr rounds of 64; nr adapts to the window
+  const int nr = static_cast<int>((cnt + kBlock - 1) / kBlock);
+  const uint32_t WSPAN = static_cast<uint32_t>(nr) * kWave;
+  const uint64_t rmask = (1ull << rbits) - 1ull;
+  uint64_t key[kLsItems];
+  uint32_t val[kLsItems];
+#pragma unroll
+  for (int r = 0; r < kLsItems; r++) {
+    const uint32_t i = w * WSPAN + r * kWave + lane;
+    key[r] = ~0ull;
+    val[r] = 0;
+    if (r < nr && i < cnt) {
+      const uint32_t v = aval[a + i];
+      const size_t t = static_cast<size_t>(v) + h;
+      const uint64_t r2 = t < n ? rank[t] + 1u : 0u;
+      key[r] = (static_cast<uint64_t>(agid[a + i] - g_first) << rbits) | r2;
+      val[r] = v;
+    }
+  }
+  const int total_bits = rbits + kLsGroupBits;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  for (int shift = 0; shift < total_bits; shift += kLsBits) {
+    for (int q = tid; q < WAVES * kLsBins; q += kBlock) (&wc[0][0])[q] = 0;
+    __syncthreads();
+    uint32_t rnk[kLsItems];
+    volatile uint32_t *mycnt = wc[w];
+#pragma unroll
+    for (int r = 0; r < kLsItems; r++) {
+      rnk[r] = 0;
+      if (r < nr) {  // wave-uniform
+        const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & (kLsBins - 1);
+        const uint64_t peers = wave_match_any_bits(d, kLsBits);
+        const int leader = __ffsll(static_cast<long long>(peers)) - 1;
+        uint32_t old = 0;
+        if (lane == leader) {
+          old = mycnt[d];
+          mycnt[d] = old + __popcll(peers);
+        }
+        old = __shfl(old, leader, kWave);
+        rnk[r] = old + __popcll(peers & lt);
+      }
+    }
+    __syncthreads();
+    // bins 4*tid .. 4*tid+3: exclusive over waves, then over bins
+    uint32_t tot4 = 0, base4[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int bin = 4 * tid + q;
+      uint32_t t = 0;
+#pragma unroll
+      for (int i = 0; i < WAVES; i++) {
+        const uint32_t c = wc[i][bin];
+        wc[i][bin] = t;
+        t += c;
+      }
+      base4[q] = tot4;
+      tot4 += t;
+    }
+    uint32_t all;
+    const uint32_t ex = block_excl_sum(tot4, ssum, all);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int bin = 4 * tid + q;
+#pragma unroll
+      for (int i = 0; i < WAVES; i++) wc[i][bin] += ex + base4[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kLsItems; r++) {
+      if (r < nr) {
+        const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & (kLsBins - 1);
+        const uint32_t pos = wc[w][d] + rnk[r];
+        skey[pos] = key[r];
+        sval[pos] = val[r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kLsItems; r++) {
+      if (r < nr) {
+        const uint32_t i = w * WSPAN + r * kWave + lane;
+        key[r] = skey[i];
+        val[r] = sval[i];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < kLsItems; r++) {
+    const uint32_t i = w * WSPAN + r * kWave + lane;
+    if (r < nr && i < cnt) {
+      const uint64_t g = static_cast<uint64_t>(g_first) + (key[r] >> rbits);
+      kout[a + i] = (g << 32) | (key[r] & rmask);
+      vout[a + i] = val[r];
+    }
+  }
+}
+
+}  // namespace wp

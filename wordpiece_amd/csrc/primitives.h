@@ -93,10 +93,19 @@ __device__ __forceinline__ int32_t block_reduce_min(int32_t v, int32_t *smem) {
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kBlock * kScanItems;
 
+// n_dev (optional): device-side element count <= n; tiles past it are skipped (their sum is 0)
 __global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const uint32_t *__restrict__ in, size_t n,
-                                                             uint32_t *__restrict__ tile_sums) {
+                                                             uint32_t *__restrict__ tile_sums,
+                                                             const uint32_t *__restrict__ n_dev) {
   __shared__ uint32_t sm[8];
   const size_t base = static_cast<size_t>(blockIdx.x) * kScanTile;
+  if (n_dev) {
+    n = min(n, static_cast<size_t>(*n_dev));
+    if (base >= n) {
+      if (threadIdx.x == 0) tile_sums[blockIdx.x] = 0;
+      return;
+    }
+  }
   uint32_t s = 0;
 #pragma unroll
   for (int j = 0; j < kScanItems; j++) {
@@ -126,8 +135,13 @@ __global__ __launch_bounds__(kBlock) void scan_spine_kernel(uint32_t *__restrict
 
 __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t *__restrict__ in,
                                                             uint32_t *__restrict__ out, size_t n,
-                                                            const uint32_t *__restrict__ tile_prefix) {
+                                                            const uint32_t *__restrict__ tile_prefix,
+                                                            const uint32_t *__restrict__ n_dev) {
   __shared__ uint32_t sm[8];
+  if (n_dev) {
+    n = min(n, static_cast<size_t>(*n_dev));
+    if (static_cast<size_t>(blockIdx.x) * kScanTile >= n) return;
+  }
   const size_t base = static_cast<size_t>(blockIdx.x) * kScanTile + static_cast<size_t>(threadIdx.x) * kScanItems;
   uint32_t v[kScanItems], s = 0;
 #pragma unroll
@@ -148,15 +162,15 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t *__re
 
 // tmp must hold cdiv(n, kScanTile) + 1 uint32; `total` (device pointer, optional) gets the sum.
 inline void device_exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, uint32_t *tmp,
-                                  uint32_t *total, hipStream_t st) {
+                                  uint32_t *total, hipStream_t st, const uint32_t *n_dev = nullptr) {
   if (n == 0) {
     if (total) WP_HIP(hipMemsetAsync(total, 0, sizeof(uint32_t), st));
     return;
   }
   unsigned tiles = cdiv(n, kScanTile);
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3(tiles), dim3(kBlock), 0, st, in, n, tmp);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(tiles), dim3(kBlock), 0, st, in, n, tmp, n_dev);
   hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(kBlock), 0, st, tmp, static_cast<size_t>(tiles), total);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3(tiles), dim3(kBlock), 0, st, in, out, n, tmp);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(tiles), dim3(kBlock), 0, st, in, out, n, tmp, n_dev);
   WP_LAUNCH_CHECK();
 }
 

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
 // single block: exclusive prefix over tiles (running max of last_flag, sums of the counts);
 // totals[0] = n_active, totals[1] = n_heads
 __global__ __launch_bounds__(kBlock) void rerank_spine_kernel(RerankAgg *__restrict__ agg, size_t tiles,
-                                                              uint32_t *__restrict__ totals) {
+                                                              uint32_t *__restrict__ totals,
+                                                              uint32_t *__restrict__ ghead) {
   __shared__ uint32_t sm[8];
   __shared__ int32_t smx[8];
   uint32_t ca = 0, ch = 0;
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(kBlock) void rerank_spine_kernel(RerankAgg *__restr
   if (threadIdx.x == 0) {
     totals[0] = ca;
     totals[1] = ch;
+    ghead[ch] = ca;  // sentinel: group g of the next list is [ghead[g], ghead[g+1])
   }
 }
 
@@ -166,7 +168,8 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ slots,
     size_t m, const RerankAgg *__restrict__ agg, const SymT *__restrict__ sym, size_t n, uint32_t h, int K,
     int bits, uint32_t *__restrict__ sa, uint32_t *__restrict__ hd, int32_t *__restrict__ lcp,
-    uint32_t *__restrict__ nslots, uint32_t *__restrict__ nvals, uint32_t *__restrict__ ngid) {
+    uint32_t *__restrict__ nslots, uint32_t *__restrict__ nvals, uint32_t *__restrict__ ngid,
+    uint32_t *__restrict__ ghead) {
   __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
   const int lane = lane_id(), w = wave_id();
   const size_t wave_base = static_cast<size_t>(blockIdx.x) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
@@ -240,7 +243,9 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
         const uint32_t pos = ea + __popcll(ba & lt);
         nslots[pos] = x;
         nvals[pos] = v;
-        ngid[pos] = eh + __popcll(bh & le) - 1;
+        const uint32_t g = eh + __popcll(bh & le) - 1;
+        ngid[pos] = g;
+        if (f) ghead[g] = pos;
       }
     }
     ea += __popcll(ba);
