@@ -145,20 +145,66 @@ __global__ __launch_bounds__(kBlock) void map_symbols_kernel(const uint32_t *__r
   sym[i] = static_cast<SymT>(lut_excl[c] + 1u);
 }
 
-// Round-0 keys: the first K symbols of every suffix packed b bits each, most significant first.
-// Suffixes running past the end are padded with 0 (< every symbol), so shorter sorts first.
+// symbol histogram (8-bit symbol path): feeds the host-side code construction (code.h)
+__global__ __launch_bounds__(kBlock) void sym_hist_kernel(const uint8_t *__restrict__ sym, size_t n,
+                                                          uint32_t *__restrict__ hist) {
+  __shared__ uint32_t sh[256];
+  sh[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t base = static_cast<size_t>(blockIdx.x) * (kBlock * 64);
+  for (int j = 0; j < 64; j++) {
+    const size_t i = base + static_cast<size_t>(j) * kBlock + threadIdx.x;
+    if (i < n) atomicAdd(&sh[sym[i]], 1u);
+  }
+  __syncthreads();
+  if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+
+// Device copy of the symbol code (code.h).  uniform_bits > 0: fixed width, tables unused.
+struct DevCode {
+  const uint16_t *cw;
+  const uint8_t *len;
+  const uint8_t *first_len;  // [4096]
+  int uniform_bits;
+};
+
+// number of complete codewords inside the first t bits of a 63-bit key (t <= 63)
+__device__ __forceinline__ int count_key_symbols(uint64_t key, int t, const uint8_t *first_len, int uniform_bits) {
+  if (uniform_bits) return t / uniform_bits;
+  int pos = 0, cnt = 0;
+  while (true) {
+    const int sh = 63 - pos - 12;
+    const uint32_t w = static_cast<uint32_t>(sh >= 0 ? (key >> sh) : (key << -sh)) & 0xfffu;
+    const int l = first_len[w];
+    if (pos + l > t) break;
+    pos += l;
+    cnt++;
+  }
+  return cnt;
+}
+
+// Round-0 keys: the first 63 bits of the codeword stream of every suffix (most significant bit
+// first).  Positions past the end read symbol 0, whose codeword is the smallest, so a shorter
+// suffix sorts first.
 constexpr int kKeyItems = 8;
 constexpr int kKeyTile = kBlock * kKeyItems;
-constexpr int kMaxK = 16;
+constexpr int kKeyHalo = 64;
 template <typename SymT>
-__global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restrict__ sym, size_t n, int K,
-                                                             int bits, uint64_t *__restrict__ keys,
+__global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restrict__ sym, size_t n, DevCode code,
+                                                             uint64_t *__restrict__ keys,
                                                              uint32_t *__restrict__ vals) {
-  __shared__ uint32_t ss[kKeyTile + kMaxK];
+  __shared__ uint32_t ss[kKeyTile + kKeyHalo];
+  __shared__ uint16_t scw[256];
+  __shared__ uint8_t slen[256];
   const size_t base = static_cast<size_t>(blockIdx.x) * kKeyTile;
-  for (int k = threadIdx.x; k < kKeyTile + kMaxK; k += kBlock) {
+  for (int k = threadIdx.x; k < kKeyTile + kKeyHalo; k += kBlock) {
     size_t i = base + k;
     ss[k] = i < n ? static_cast<uint32_t>(sym[i]) : 0u;
+  }
+  const int ub = code.uniform_bits;
+  if (!ub) {
+    scw[threadIdx.x] = code.cw[threadIdx.x];
+    slen[threadIdx.x] = code.len[threadIdx.x];
   }
   __syncthreads();
 #pragma unroll
@@ -167,7 +213,15 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
     const size_t i = base + li;
     if (i < n) {
       uint64_t key = 0;
-      for (int k = 0; k < K; k++) key = (key << bits) | ss[li + k];
+      int used = 0, q = li;
+      while (used < 63) {
+        const uint32_t sv = ss[q++];
+        const int l = ub ? ub : slen[sv];
+        const uint32_t c = ub ? sv : scw[sv];
+        const int take = min(l, 63 - used);
+        key = (key << take) | (c >> (l - take));
+        used += take;
+      }
       keys[i] = key;
       vals[i] = static_cast<uint32_t>(i);
     }

@@ -15,6 +15,7 @@
 #include <memory>
 
 #include "../../include/wordpiece_amd.h"
+#include "code.h"
 #include "decode.h"
 #include "local_sort.h"
 #include "radix_sort.h"
@@ -85,6 +86,8 @@ struct Context {
   DeviceBuffer text_buf, a_buf, b_buf;
   uint32_t *d_used = nullptr, *d_lut = nullptr, *d_scan_tmp = nullptr;  // code point tables
   uint32_t *d_scalars = nullptr;                                         // 16 words of device scalars
+  uint8_t *d_code = nullptr;     // symbol code tables: cw u16[256] | len u8[256] | first_len u8[4096]
+  uint32_t *d_symhist = nullptr;  // 256 counters
   uint32_t *h_scalars = nullptr;                                         // pinned mirror
   RadixStats rstats;
   hipEvent_t ev[8] = {};
@@ -93,7 +96,8 @@ struct Context {
   struct {
     const void *sym = nullptr;
     int sym_bytes = 0;
-    const uint32_t *sa = nullptr, *rank = nullptr, *cps = nullptr;
+    const uint32_t *sa = nullptr, *cps = nullptr;
+    const RankEntry *rank = nullptr;
     const int32_t *lcp = nullptr, *bestp = nullptr, *bests = nullptr;
     size_t n = 0, n_text = 0;
   } dbg;
@@ -121,7 +125,8 @@ static void destroy_context(Context *c) {
                   static_cast<void *>(c->d_elig_info), static_cast<void *>(c->d_soft),
                   static_cast<void *>(c->d_elig_id), static_cast<void *>(c->d_tok_len),
                   static_cast<void *>(c->d_used), static_cast<void *>(c->d_lut), static_cast<void *>(c->d_scan_tmp),
-                  static_cast<void *>(c->d_scalars)}) {
+                  static_cast<void *>(c->d_scalars), static_cast<void *>(c->d_code),
+                  static_cast<void *>(c->d_symhist)}) {
     if (p) (void)hipFree(p);
   }
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
@@ -170,6 +175,8 @@ static Context *get_context(wp_vocab *v) {
   WP_HIP(hipMalloc(&c->d_lut, sizeof(uint32_t) * kCpTableSize));
   WP_HIP(hipMalloc(&c->d_scan_tmp, sizeof(uint32_t) * (cdiv(kCpTableSize, kScanTile) + 8)));
   WP_HIP(hipMalloc(&c->d_scalars, sizeof(uint32_t) * 16));
+  WP_HIP(hipMalloc(&c->d_code, 512 + 256 + 4096));
+  WP_HIP(hipMalloc(&c->d_symhist, sizeof(uint32_t) * 256));
   WP_HIP(hipHostMalloc(&c->h_scalars, sizeof(uint32_t) * 16));
   for (auto &e : c->ev) WP_HIP(hipEventCreate(&e));
   WP_HIP(hipStreamSynchronize(c->stream));
@@ -260,11 +267,9 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   hipStream_t st = c->stream;
   const HostVocab &hv = v->hv;
   wp_stats &S = v->stats;
-  const int K = std::max(1, std::min(kMaxK, 64 / bits));
   const bool full = v->full_depth || hv.n_dup_eligible > 0 || v->lcp_kasai;
   const uint32_t need_depth = static_cast<uint32_t>(std::min<int64_t>(hv.longest + 1, 0x7fffffff));
   S.symbol_bits = bits;
-  S.symbols_per_key = K;
   S.full_depth = full;
 
   const int M = static_cast<int>(hv.elig_id.size());
@@ -279,8 +284,10 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
 
   SymT *d_sym = nullptr;
   uint64_t *K0 = nullptr, *K1 = nullptr;
+  RankEntry *d_rank = nullptr;
+  uint32_t *AD0 = nullptr, *AD1 = nullptr, *d_tdep = nullptr;
   uint32_t *V0 = nullptr, *V1 = nullptr, *AS0 = nullptr, *AS1 = nullptr, *AG = nullptr, *d_sa = nullptr,
-           *d_rank = nullptr, *d_radix_tmp = nullptr, *d_mslot0 = nullptr, *d_mslot1 = nullptr, *d_midx0 = nullptr,
+           *d_radix_tmp = nullptr, *d_mslot0 = nullptr, *d_mslot1 = nullptr, *d_midx0 = nullptr,
            *d_midx1 = nullptr, *d_minfo = nullptr, *d_tile_mlo = nullptr, *d_depth = nullptr, *d_emit_cnt = nullptr,
            *d_emit_tmp = nullptr;
   int32_t *d_lcp = nullptr, *d_mid = nullptr, *d_interior = nullptr, *d_rf = nullptr, *d_rb = nullptr;
@@ -302,7 +309,10 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     AS1 = ar.take<uint32_t>(n);
     AG = ar.take<uint32_t>(n);
     d_sa = ar.take<uint32_t>(n);
-    d_rank = ar.take<uint32_t>(n);
+    d_rank = ar.take<RankEntry>(n);
+    AD0 = ar.take<uint32_t>(n);
+    AD1 = ar.take<uint32_t>(n);
+    d_tdep = ar.take<uint32_t>(n);
     d_lcp = ar.take<int32_t>(n);
     d_radix_tmp = ar.take<uint32_t>(radix_words);
     d_ghead = ar.take<uint32_t>(n / 2 + 4);
@@ -337,16 +347,43 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     if (pass == 0) ar.commit();
   }
 
-  // ---------------- S build: dense symbols, round-0 keys ----------------
+  // ---------------- S build: dense symbols, symbol code, round-0 keys ----------------
   hipLaunchKernelGGL(HIP_KERNEL_NAME(map_symbols_kernel<SymT>), dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, d_cps,
                      n_text, c->d_stream, n, c->d_lut, d_sym);
+  SymbolCode code;
+  static const bool allow_variable = !(getenv("WP_FIXED_CODE") && atoi(getenv("WP_FIXED_CODE")) != 0);
+  if (sizeof(SymT) == 1 && allow_variable) {
+    // symbol frequencies -> optimal order-preserving code (host, <= 256 symbols) -> device tables
+    WP_HIP(hipMemsetAsync(c->d_symhist, 0, sizeof(uint32_t) * 256, st));
+    hipLaunchKernelGGL(sym_hist_kernel, dim3(cdiv(n, kBlock * 64)), dim3(kBlock), 0, st,
+                       reinterpret_cast<const uint8_t *>(d_sym), n, c->d_symhist);
+    std::vector<uint32_t> h32(256);
+    WP_HIP(hipMemcpyAsync(h32.data(), c->d_symhist, sizeof(uint32_t) * 256, hipMemcpyDeviceToHost, st));
+    WP_HIP(hipStreamSynchronize(st));
+    const size_t nsym = static_cast<size_t>(S.alphabet) + 1;  // dense symbols 0..sigma
+    std::vector<uint64_t> freq(nsym);
+    for (size_t i = 0; i < nsym; i++) freq[i] = h32[i];
+    code = build_symbol_code(freq, bits, true);
+  } else {
+    code = build_symbol_code({}, bits, false);
+  }
+  DevCode dcode{reinterpret_cast<const uint16_t *>(c->d_code), c->d_code + 512, c->d_code + 768, code.uniform_bits};
+  if (!code.uniform_bits) {
+    std::vector<uint8_t> blob(512 + 256 + 4096, 0);
+    std::memcpy(blob.data(), code.cw.data(), code.cw.size() * sizeof(uint16_t));
+    std::memcpy(blob.data() + 512, code.len.data(), code.len.size());
+    std::memcpy(blob.data() + 768, code.first_len.data(), 4096);
+    WP_HIP(hipMemcpyAsync(c->d_code, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+    WP_HIP(hipStreamSynchronize(st));  // blob is a stack object
+  }
+  S.symbols_per_key = static_cast<int32_t>(kKeyBits / std::max(1.0, code.avg_bits));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(build_keys0_kernel<SymT>), dim3(cdiv(n, kKeyTile)), dim3(kBlock), 0, st, d_sym,
-                     n, K, bits, K0, V0);
+                     n, dcode, K0, V0);
   WP_LAUNCH_CHECK();
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[2], st));
 
   // ---------------- suffix array by prefix doubling ----------------
-  static const bool use_local = !(getenv("WP_LOCAL_SORT") && atoi(getenv("WP_LOCAL_SORT")) == 0);
+  const DepthRule rule{need_depth, full ? 1 : 0};
   // after every rerank: classify the new groups (large ones take the global path next round)
   auto classify_groups = [&](size_t list_len) {
     const size_t cap = list_len / 2 + 1;  // a group has >= 2 entries
@@ -355,95 +392,79 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     device_exclusive_scan(d_large_id, d_large_id, cap, d_gscan_tmp, c->d_scalars + 6, st, c->d_scalars + 5);
     device_exclusive_scan(d_large_off, d_large_off, cap, d_gscan_tmp, c->d_scalars + 7, st, c->d_scalars + 5);
   };
-  int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, K * bits, d_radix_tmp, st, &c->rstats);
+  int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, kKeyBits, d_radix_tmp, st, &c->rstats);
   uint64_t *keys = cur ? K1 : K0;
   uint32_t *vals = cur ? V1 : V0, *other_vals = cur ? V0 : V1;
   uint32_t *slots = AS0, *other_slots = AS1;
+  uint32_t *adep = AD0, *other_dep = AD1;
   {
     const unsigned tiles = cdiv(n, kRrTile);
-    hipLaunchKernelGGL(rerank_agg_kernel, dim3(tiles), dim3(kBlock), 0, st, keys, n, d_agg);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<true>), dim3(tiles), dim3(kBlock), 0, st, keys, vals, n,
+                       static_cast<const uint32_t *>(nullptr), static_cast<const RankEntry *>(nullptr), n,
+                       dcode.first_len, dcode.uniform_bits, rule, d_tdep, d_agg);
     hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kBlock), 0, st, d_agg, static_cast<size_t>(tiles),
                        c->d_scalars + 4, d_ghead);
-    uint64_t *kother = cur ? K0 : K1;
-    uint32_t *hd = reinterpret_cast<uint32_t *>(kother);
+    RankEntry *hd = reinterpret_cast<RankEntry *>(cur ? K0 : K1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
-                       vals, static_cast<const uint32_t *>(nullptr), n, d_agg, d_sym, n, 0u, K, bits, d_sa, hd,
-                       d_lcp, slots, other_vals, AG, d_ghead);
+                       vals, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), d_tdep, n,
+                       d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp, slots, other_vals,
+                       AG, adep, d_ghead);
     hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, vals, hd, n, d_rank);
     WP_LAUNCH_CHECK();
-    if (use_local) classify_groups(n);
+    classify_groups(n);
   }
   fetch_scalars(c, 8);
   size_t n_act = c->h_scalars[4], n_groups = c->h_scalars[5];
-  size_t n_large_groups = use_local ? c->h_scalars[6] : 0, n_large = use_local ? c->h_scalars[7] : 0;
-  uint64_t depth = static_cast<uint64_t>(K);
+  size_t n_large_groups = c->h_scalars[6], n_large = c->h_scalars[7];
   int rounds = 1;
   S.active_per_round[0] = static_cast<int64_t>(n);
   uint32_t *avals = other_vals;  // active list values live in the vals buffer the sort did not end in
   uint32_t *spare_vals = vals;
-  while (n_act > 0 && (full || depth < need_depth)) {
+  const int rb = bit_length(n);  // rank+1 <= n
+  while (n_act > 0) {
     if (rounds < 40) S.active_per_round[rounds] = static_cast<int64_t>(n_act);
-    const uint32_t h = static_cast<uint32_t>(std::min<uint64_t>(depth, 0x7fffffffu));
-    const int rb = bit_length(n);  // rank+1 <= n
-    uint64_t *skeys, *kfree;
-    uint32_t *svals, *nvals;
-    if (use_local) {
-      // small groups: one LDS-resident segmented sort per window of the list
-      skeys = K0;
-      kfree = K1;
-      svals = spare_vals;
-      nvals = avals;  // free again once the sorts have consumed it
-      hipLaunchKernelGGL(local_sort_kernel, dim3(cdiv(n_act, kLsT)), dim3(kBlock), 0, st, avals, AG, n_act, d_ghead,
-                         static_cast<uint32_t>(n_groups), d_rank, h, n, rb, skeys, svals);
-      if (n_large > 0) {  // large groups: extract, global radix sort on (dense large id, rank[i+h]), write back
-        hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, avals, AG, n_act,
-                           d_ghead, d_large_id, d_large_off, d_rank, h, n, K1, LV0, LPOS);
-        const int lgb = bit_length(n_large_groups > 0 ? n_large_groups - 1 : 0);
-        const BitRange ranges[2] = {{0, rb}, {32, 32 + lgb}};
-        const int lc = radix_sort_ranges<uint64_t>(K1, LV0, LK1, LV1, n_large, ranges, lgb > 0 ? 2 : 1, d_radix_tmp,
-                                                   st, &c->rstats);
-        hipLaunchKernelGGL(large_writeback_kernel, dim3(cdiv(n_large, kBlock)), dim3(kBlock), 0, st,
-                           lc ? LK1 : K1, lc ? LV1 : LV0, LPOS, n_large, AG, skeys, svals);
-      }
-      WP_LAUNCH_CHECK();
-    } else {
-      hipLaunchKernelGGL(build_keys_round_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, avals, AG, n_act,
-                         d_rank, h, n, K0);
-      const int gb = bit_length(n_groups > 0 ? n_groups - 1 : 0);
-      const BitRange ranges[2] = {{0, rb}, {32, 32 + gb}};
-      const int cc = radix_sort_ranges<uint64_t>(K0, avals, K1, spare_vals, n_act, ranges, gb > 0 ? 2 : 1,
-                                                 d_radix_tmp, st, &c->rstats);
-      skeys = cc ? K1 : K0;
-      kfree = cc ? K0 : K1;
-      svals = cc ? spare_vals : avals;
-      nvals = cc ? avals : spare_vals;
+    // small groups: one LDS-resident segmented sort per window of the list
+    uint64_t *skeys = K0, *kfree = K1;
+    uint32_t *svals = spare_vals, *nvals = avals;  // avals is free again once the sorts have consumed it
+    hipLaunchKernelGGL(local_sort_kernel, dim3(cdiv(n_act, kLsT)), dim3(kBlock), 0, st, avals, AG, adep, n_act,
+                       d_ghead, static_cast<uint32_t>(n_groups), d_rank, n, rb, skeys, svals);
+    if (n_large > 0) {  // large groups: extract, global radix sort on (dense large id, second key), write back
+      hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, avals, AG, adep, n_act,
+                         d_ghead, d_large_id, d_large_off, d_rank, n, K1, LV0, LPOS);
+      const int lgb = bit_length(n_large_groups > 0 ? n_large_groups - 1 : 0);
+      const BitRange ranges[2] = {{0, rb}, {32, 32 + lgb}};
+      const int lc = radix_sort_ranges<uint64_t>(K1, LV0, LK1, LV1, n_large, ranges, lgb > 0 ? 2 : 1, d_radix_tmp, st,
+                                                 &c->rstats);
+      hipLaunchKernelGGL(large_writeback_kernel, dim3(cdiv(n_large, kBlock)), dim3(kBlock), 0, st, lc ? LK1 : K1,
+                         lc ? LV1 : LV0, LPOS, n_large, AG, skeys, svals);
     }
     const unsigned tiles = cdiv(n_act, kRrTile);
-    hipLaunchKernelGGL(rerank_agg_kernel, dim3(tiles), dim3(kBlock), 0, st, skeys, n_act, d_agg);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<false>), dim3(tiles), dim3(kBlock), 0, st, skeys, svals,
+                       n_act, adep, d_rank, n, dcode.first_len, dcode.uniform_bits, rule, d_tdep, d_agg);
     hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kBlock), 0, st, d_agg, static_cast<size_t>(tiles),
                        c->d_scalars + 4, d_ghead);
-    uint32_t *hd = reinterpret_cast<uint32_t *>(kfree);
+    RankEntry *hd = reinterpret_cast<RankEntry *>(kfree);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
-                       svals, slots, n_act, d_agg, d_sym, n, h, K, bits, d_sa, hd, d_lcp, other_slots, nvals, AG,
-                       d_ghead);
+                       svals, slots, adep, d_tdep, n_act, d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule,
+                       d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead);
     hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, svals, hd, n_act,
                        d_rank);
     WP_LAUNCH_CHECK();
-    if (use_local) classify_groups(n_act);
+    classify_groups(n_act);
     fetch_scalars(c, 8);
     n_act = c->h_scalars[4];
     n_groups = c->h_scalars[5];
-    n_large_groups = use_local ? c->h_scalars[6] : 0;
-    n_large = use_local ? c->h_scalars[7] : 0;
+    n_large_groups = c->h_scalars[6];
+    n_large = c->h_scalars[7];
     std::swap(slots, other_slots);
+    std::swap(adep, other_dep);
     avals = nvals;
     spare_vals = svals;
-    depth *= 2;
     rounds++;
   }
   S.rounds = rounds;
-  S.sorted_depth = static_cast<int32_t>(std::min<uint64_t>(depth, 0x7fffffffu));
-  if (n_act == 0) S.sorted_depth = 0x7fffffff;
+  // every tie that is left shares at least need_depth symbols (depth-capped mode)
+  S.sorted_depth = full ? 0x7fffffff : static_cast<int32_t>(need_depth);
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[3], st));
 
   if (v->lcp_kasai) {  // alternative LCP builder: chunked Kasai exactly as linear.cpp:18-70
@@ -784,7 +805,11 @@ int wp_linear_debug_fetch(const wp_vocab *v, int which, int32_t *out, size_t cap
     if (cnt > capacity) throw std::invalid_argument("debug buffer too small");
     *n_out = cnt;
     if (cnt == 0) return;
-    if (which == 0 && d.sym_bytes == 1) {
+    if (which == 2) {
+      std::vector<RankEntry> tmp(cnt);
+      WP_HIP(hipMemcpy(tmp.data(), src, cnt * sizeof(RankEntry), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < cnt; i++) out[i] = static_cast<int32_t>(rank_of(tmp[i]));
+    } else if (which == 0 && d.sym_bytes == 1) {
       std::vector<uint8_t> tmp(cnt);
       WP_HIP(hipMemcpy(tmp.data(), src, cnt, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < cnt; i++) out[i] = tmp[i];

@@ -1,7 +1,7 @@
 // local_sort.h — segmented sort of the active list for prefix-doubling rounds r >= 1.
 //
 // In round r every still-tied group (contiguous in the active list) must be sorted by
-// rank[i+h].  Most groups are small (after 9 symbols of English text 79 % of the active
+// rank[i + depth(group)].  Most groups are small (after 9 symbols of English text 79 % of the active
 // entries sit in groups of <= 2048), so a workgroup takes a window of whole groups into LDS,
 // gathers their second keys and sorts the window there with 10-bit LSD passes on the composite
 // (local group number, rank[i+h]+1): no HBM pass per digit, one read and one write per entry.
@@ -12,6 +12,7 @@
 // entries.
 #pragma once
 #include "primitives.h"
+#include "suffix_array.h"
 
 namespace wp {
 
@@ -56,9 +57,9 @@ __global__ __launch_bounds__(kBlock) void group_classify_kernel(const uint32_t *
 
 // entries of large groups -> (key, val, list position) in the large list
 __global__ __launch_bounds__(kBlock) void large_extract_kernel(
-    const uint32_t *__restrict__ aval, const uint32_t *__restrict__ agid, size_t m,
-    const uint32_t *__restrict__ ghead, const uint32_t *__restrict__ large_id,
-    const uint32_t *__restrict__ large_off, const uint32_t *__restrict__ rank, uint32_t h, size_t n,
+    const uint32_t *__restrict__ aval, const uint32_t *__restrict__ agid, const uint32_t *__restrict__ adep,
+    size_t m, const uint32_t *__restrict__ ghead, const uint32_t *__restrict__ large_id,
+    const uint32_t *__restrict__ large_off, const RankEntry *__restrict__ rank, size_t n,
     uint64_t *__restrict__ lkey, uint32_t *__restrict__ lval, uint32_t *__restrict__ lpos) {
   const size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (k >= m) return;
@@ -67,8 +68,8 @@ __global__ __launch_bounds__(kBlock) void large_extract_kernel(
   if (ghead[g + 1] - h0 <= kLsMaxGroup) return;
   const uint32_t j = large_off[g] + (static_cast<uint32_t>(k) - h0);
   const uint32_t v = aval[k];
-  const size_t t = static_cast<size_t>(v) + h;
-  const uint32_t r2 = t < n ? rank[t] + 1u : 0u;
+  const size_t t = static_cast<size_t>(v) + adep[k];
+  const uint32_t r2 = t < n ? rank_of(rank[t]) + 1u : 0u;
   lkey[j] = (static_cast<uint64_t>(large_id[g]) << 32) | r2;
   lval[j] = v;
   lpos[j] = static_cast<uint32_t>(k);
@@ -89,10 +90,11 @@ __global__ __launch_bounds__(kBlock) void large_writeback_kernel(const uint64_t 
 }
 
 __global__ __launch_bounds__(kBlock) void local_sort_kernel(const uint32_t *__restrict__ aval,
-                                                            const uint32_t *__restrict__ agid, size_t m,
+                                                            const uint32_t *__restrict__ agid,
+                                                            const uint32_t *__restrict__ adep, size_t m,
                                                             const uint32_t *__restrict__ ghead, uint32_t n_groups,
-                                                            const uint32_t *__restrict__ rank, uint32_t h, size_t n,
-                                                            int rbits, uint64_t *__restrict__ kout,
+                                                            const RankEntry *__restrict__ rank, size_t n, int rbits,
+                                                            uint64_t *__restrict__ kout,
                                                             uint32_t *__restrict__ vout) {
   constexpr int WAVES = kBlock / kWave;
   __shared__ uint64_t skey[kLsCap];
@@ -131,8 +133,8 @@ __global__ __launch_bounds__(kBlock) void local_sort_kernel(const uint32_t *__re
     val[r] = 0;
     if (r < nr && i < cnt) {
       const uint32_t v = aval[a + i];
-      const size_t t = static_cast<size_t>(v) + h;
-      const uint64_t r2 = t < n ? rank[t] + 1u : 0u;
+      const size_t t = static_cast<size_t>(v) + adep[a + i];
+      const uint64_t r2 = t < n ? rank_of(rank[t]) + 1u : 0u;
       key[r] = (static_cast<uint64_t>(agid[a + i] - g_first) << rbits) | r2;
       val[r] = v;
     }

@@ -15,6 +15,7 @@
 // Marks (vocab token starts) are a sorted list of (slot, id, len, class), not a dense who[] array.
 #pragma once
 #include "primitives.h"
+#include "suffix_array.h"
 
 namespace wp {
 
@@ -40,11 +41,11 @@ __device__ __forceinline__ int32_t boundary_lcp(const int32_t *__restrict__ lcp,
 
 // who marks: slot of every eligible token's first symbol (linear.cpp:153-160)
 __global__ __launch_bounds__(kBlock) void mark_slots_kernel(const uint32_t *__restrict__ tok_start, int M,
-                                                            size_t vocab_base, const uint32_t *__restrict__ rank,
+                                                            size_t vocab_base, const RankEntry *__restrict__ rank,
                                                             uint32_t *__restrict__ slot, uint32_t *__restrict__ idx) {
   int m = blockIdx.x * kBlock + threadIdx.x;
   if (m >= M) return;
-  slot[m] = rank[vocab_base + tok_start[m]];
+  slot[m] = rank_of(rank[vocab_base + tok_start[m]]);
   idx[m] = static_cast<uint32_t>(m);
 }
 

@@ -1,17 +1,20 @@
 // suffix_array.h — suffix array + rank + LCP by prefix doubling (replaces libsais_int,
 // the inverse-SA loop and calcLcp: linear.cpp:118-149).
 //
-// Round 0 sorts every suffix by its first K symbols packed into one 64-bit key (LSD radix).
-// Round r >= 1 works on the *active list* only — the slots of groups that are still tied —
-// sorting (dense group id, rank[i+h]) and splitting groups; singletons retire.  rank[i] is
-// the first SA slot of i's group, so a retired suffix already holds its final rank.
+// Round 0 sorts every suffix by the first 63 bits of its codeword stream (code.h) with an LSD
+// radix sort.  Round r >= 1 works on the *active list* only — the slots of groups that are still
+// tied — sorting every group by rank[i + depth(group)] and splitting it; singletons (and, in the
+// depth-capped mode, groups whose depth already exceeds the longest vocab token) retire.  rank[i]
+// is the first SA slot of i's group, so a retired suffix already holds its final rank.  Depths are
+// per group: depth(new subgroup) = depth(old group) + depth(group of the second key).
 //
 // LCP comes out of the same passes: a boundary that appears in round 0 gets its LCP from the two
-// packed keys (count of equal leading symbols); a boundary that appears in the round with offset
-// h separates two suffixes that agree on exactly h symbols plus whatever their (i+h, j+h)
-// continuations share, which is < h, so it is one bounded symbol compare.  Boundaries that never
-// appear (depth-capped mode) keep -1 = "LCP >= sorted depth".
+// keys (complete codewords inside their common bit prefix); a boundary that appears later
+// separates two suffixes that share the old group's depth d, so it is d + one direct symbol
+// compare from offset d.  Boundaries that never appear (depth-capped mode) keep -1 = "LCP >= the
+// depth cap".
 #pragma once
+#include "decode.h"
 #include "primitives.h"
 
 namespace wp {
@@ -19,23 +22,23 @@ namespace wp {
 constexpr int kRrItems = 8;
 constexpr int kRrTile = kBlock * kRrItems;  // 2048 list entries per workgroup
 
+// rank table entry of a text position: low word = rank (first SA slot of its group), high word =
+// the group's depth (symbols its members are known to share; meaningful for tied groups only)
+using RankEntry = uint64_t;
+__host__ __device__ inline uint32_t rank_of(RankEntry e) { return static_cast<uint32_t>(e); }
+__host__ __device__ inline uint32_t depth_of(RankEntry e) { return static_cast<uint32_t>(e >> 32); }
+constexpr uint64_t kRankUnchanged = ~0ull;
+
 struct RerankAgg {
   uint32_t last_flag;  // 1 + largest k in the tile that starts a group, 0 if none
-  uint32_t n_active;   // entries of non-singleton groups
-  uint32_t n_heads;    // heads of non-singleton groups
+  uint32_t n_active;   // entries that stay on the active list
+  uint32_t n_heads;    // heads of groups that stay on the active list
 };
 
-// keys for round r >= 1 over the active list: (dense group id << 32) | (rank[i+h]+1, 0 past the end)
-__global__ __launch_bounds__(kBlock) void build_keys_round_kernel(const uint32_t *__restrict__ aval,
-                                                                  const uint32_t *__restrict__ agid, size_t n_act,
-                                                                  const uint32_t *__restrict__ rank, uint32_t h,
-                                                                  size_t n, uint64_t *__restrict__ keys) {
-  size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (k >= n_act) return;
-  const size_t j = static_cast<size_t>(aval[k]) + h;
-  const uint32_t r2 = j < n ? rank[j] + 1u : 0u;
-  keys[k] = (static_cast<uint64_t>(agid[k]) << 32) | r2;
-}
+struct DepthRule {
+  uint32_t need;  // a tied group retires once its depth reaches this (depth-capped mode)
+  int full;       // 1: only singletons retire (true suffix array)
+};
 
 __device__ __forceinline__ void rr_flags(const uint64_t *__restrict__ keys, size_t m, size_t k, bool &flag,
                                          bool &single) {
@@ -50,18 +53,47 @@ __device__ __forceinline__ void rr_flags(const uint64_t *__restrict__ keys, size
 constexpr int kRrRounds = kRrItems;
 constexpr int kRrWaveSpan = kWave * kRrRounds;
 
-__global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__restrict__ keys, size_t m,
+// Pass 1 over the sorted list: group flags, the new depth of every tied entry (tdep) and the
+// per-tile counts.  ROUND0: depth = complete codewords inside the 63-bit key; later rounds:
+// depth = old depth + depth of the group the second key came from.
+template <bool ROUND0>
+__global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__restrict__ keys,
+                                                            const uint32_t *__restrict__ vals, size_t m,
+                                                            const uint32_t *__restrict__ adep,
+                                                            const RankEntry *__restrict__ rd, size_t n,
+                                                            const uint8_t *__restrict__ first_len, int uniform_bits,
+                                                            DepthRule rule, uint32_t *__restrict__ tdep,
                                                             RerankAgg *__restrict__ agg) {
   __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
+  __shared__ uint8_t s_fl[1 << 12];
+  if (ROUND0 && !uniform_bits) {
+    for (int q = threadIdx.x; q < (1 << 12); q += kBlock) s_fl[q] = first_len[q];
+    __syncthreads();
+  }
   const int lane = lane_id(), w = wave_id();
   const size_t wave_base = static_cast<size_t>(blockIdx.x) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
   uint32_t na = 0, nh = 0, last = 0;  // last: 1 + list index of the last group head seen, 0 = none
 #pragma unroll
   for (int r = 0; r < kRrRounds; r++) {
     const size_t k = wave_base + static_cast<size_t>(r) * kWave + lane;
-    bool f = false, sg = true;
-    if (k < m) rr_flags(keys, m, k, f, sg);
-    const uint64_t bf = __ballot(f), ba = __ballot(k < m && !sg), bh = __ballot(f && !sg);
+    bool f = false, sg = true, act = false;
+    if (k < m) {
+      rr_flags(keys, m, k, f, sg);
+      if (!sg) {
+        uint32_t nd;
+        if (ROUND0) {
+          nd = static_cast<uint32_t>(count_key_symbols(keys[k], 63, s_fl, uniform_bits));
+        } else {
+          const uint32_t d = adep[k];
+          const size_t t = static_cast<size_t>(vals[k]) + d;
+          const uint32_t dj = t < n ? depth_of(rd[t]) : 0u;
+          nd = min(d + dj, 0x7fffffffu);
+        }
+        tdep[k] = nd;
+        act = rule.full || nd < rule.need;
+      }
+    }
+    const uint64_t bf = __ballot(f), ba = __ballot(act), bh = __ballot(f && act);
     na += __popcll(ba);
     nh += __popcll(bh);
     if (bf) last = static_cast<uint32_t>(wave_base + static_cast<size_t>(r) * kWave + (63 - __clzll(static_cast<long long>(bf))) + 1);
@@ -88,6 +120,7 @@ __global__ __launch_bounds__(kBlock) void rerank_spine_kernel(RerankAgg *__restr
                                                               uint32_t *__restrict__ ghead) {
   __shared__ uint32_t sm[8];
   __shared__ int32_t smx[8];
+  __shared__ int32_t shifted[kBlock];
   uint32_t ca = 0, ch = 0;
   int32_t cm = 0;
   for (size_t base = 0; base < tiles; base += kBlock) {
@@ -99,7 +132,6 @@ __global__ __launch_bounds__(kBlock) void rerank_spine_kernel(RerankAgg *__restr
     uint32_t eh = block_excl_sum(a.n_heads, sm, th);
     // exclusive running max: shift by one thread
     int32_t inc = block_incl_max(static_cast<int32_t>(a.last_flag), smx);
-    __shared__ int32_t shifted[kBlock];
     __syncthreads();
     shifted[threadIdx.x] = inc;
     __syncthreads();
@@ -153,24 +185,31 @@ __device__ __forceinline__ int32_t lcp_compare(const SymT *__restrict__ sym, siz
 }
 
 __global__ __launch_bounds__(kBlock) void scatter_pairs_kernel(const uint32_t *__restrict__ dst,
-                                                               const uint32_t *__restrict__ val, size_t m,
-                                                               uint32_t *__restrict__ out) {
+                                                               const RankEntry *__restrict__ val, size_t m,
+                                                               RankEntry *__restrict__ out) {
   size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (k < m) {
-    const uint32_t v = val[k];
-    if (v != 0xffffffffu) out[dst[k]] = v;  // 0xffffffff = rank unchanged this round
+    const RankEntry v = val[k];
+    if (v != kRankUnchanged) out[dst[k]] = v;
   }
 }
 
-// Applies one round's split.  ROUND0: list == all slots (slot k == k), keys are packed symbols.
+// Pass 2: applies one round's split.  ROUND0: list == all slots (slot k == k), keys are the packed
+// codeword streams.  Later rounds: keys = (group id << 32 | second key), adep = depth of the
+// entry's (old) group.
 template <typename SymT, bool ROUND0>
 __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ slots,
-    size_t m, const RerankAgg *__restrict__ agg, const SymT *__restrict__ sym, size_t n, uint32_t h, int K,
-    int bits, uint32_t *__restrict__ sa, uint32_t *__restrict__ hd, int32_t *__restrict__ lcp,
-    uint32_t *__restrict__ nslots, uint32_t *__restrict__ nvals, uint32_t *__restrict__ ngid,
-    uint32_t *__restrict__ ghead) {
+    const uint32_t *__restrict__ adep, const uint32_t *__restrict__ tdep, size_t m,
+    const RerankAgg *__restrict__ agg, const SymT *__restrict__ sym, size_t n, const uint8_t *__restrict__ first_len,
+    int uniform_bits, DepthRule rule, uint32_t *__restrict__ sa, RankEntry *__restrict__ hd,
+    int32_t *__restrict__ lcp, uint32_t *__restrict__ nslots, uint32_t *__restrict__ nvals,
+    uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep, uint32_t *__restrict__ ghead) {
   __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
+  __shared__ uint8_t s_fl[1 << 12];
+  if (ROUND0 && !uniform_bits) {
+    for (int q = threadIdx.x; q < (1 << 12); q += kBlock) s_fl[q] = first_len[q];
+  }
   const int lane = lane_id(), w = wave_id();
   const size_t wave_base = static_cast<size_t>(blockIdx.x) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
   const RerankAgg pre = agg[blockIdx.x];
@@ -181,11 +220,14 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
 #pragma unroll
   for (int r = 0; r < kRrRounds; r++) {
     const size_t k = wave_base + static_cast<size_t>(r) * kWave + lane;
-    bool f = false, sg = true;
-    if (k < m) rr_flags(keys, m, k, f, sg);
+    bool f = false, sg = true, act = false;
+    if (k < m) {
+      rr_flags(keys, m, k, f, sg);
+      if (!sg) act = rule.full || tdep[k] < rule.need;
+    }
     bfs[r] = __ballot(f);
-    bas[r] = __ballot(k < m && !sg);
-    bhs[r] = __ballot(f && !sg);
+    bas[r] = __ballot(act);
+    bhs[r] = __ballot(f && act);
     na += __popcll(bas[r]);
     nh += __popcll(bhs[r]);
     if (bfs[r]) last = static_cast<uint32_t>(wave_base + static_cast<size_t>(r) * kWave + (63 - __clzll(static_cast<long long>(bfs[r]))) + 1);
@@ -217,34 +259,39 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
       const uint32_t v = vals[k];
       const uint32_t x = ROUND0 ? static_cast<uint32_t>(k) : slots[k];
       const uint32_t head_slot = ROUND0 ? static_cast<uint32_t>(head) : slots[head];
+      const uint64_t me = keys[k];
+      const bool single = f && (k + 1 == m || keys[k + 1] != me);
       sa[x] = v;
-      // new rank of suffix v, scattered to rank[v] afterwards; in rounds >= 1 the first subgroup of
-      // an old group keeps its rank (its head is the old head): marked "unchanged"
+      // new rank entry of suffix v, scattered to the rank table afterwards.  In rounds >= 1 the
+      // first subgroup of an old group keeps its rank (its head is the old head): left unchanged.
       bool changed = true;
       if (!ROUND0) changed = head > 0 && (keys[head] >> 32) == (keys[head - 1] >> 32);
-      hd[k] = changed ? head_slot : 0xffffffffu;
+      const uint32_t nd = single ? 0u : tdep[k];
+      hd[k] = changed ? ((static_cast<uint64_t>(nd) << 32) | head_slot) : kRankUnchanged;
       if (ROUND0) {
         if (k > 0) {
           int32_t l = -1;
           if (f) {
-            const uint64_t d = keys[k] ^ keys[k - 1];
-            const int lead = __clzll(static_cast<long long>(d)) - (64 - K * bits);
-            l = lead / bits;
+            const uint64_t d = me ^ keys[k - 1];
+            l = count_key_symbols(me, __clzll(static_cast<long long>(d)) - 1, s_fl, uniform_bits);
           }
           lcp[x - 1] = l;
         }
-      } else if (f && k > 0 && (keys[k] >> 32) == (keys[k - 1] >> 32)) {
-        // a new boundary inside an old group: x-1 is the previous list entry's slot
-        lcp[x - 1] = static_cast<int32_t>(h)
-                     + lcp_compare(sym, n, static_cast<size_t>(vals[k - 1]) + h, static_cast<size_t>(v) + h,
-                                   static_cast<int32_t>(h));
+      } else if (f && k > 0 && (me >> 32) == (keys[k - 1] >> 32)) {
+        // a new boundary inside an old group (x-1 is the previous list entry's slot): the two
+        // suffixes share the old group's depth and then differ within the second keys' reach
+        const uint32_t d = adep[k];
+        lcp[x - 1] = static_cast<int32_t>(d)
+                     + lcp_compare(sym, n, static_cast<size_t>(vals[k - 1]) + d, static_cast<size_t>(v) + d,
+                                   0x7fffffff);
       }
       if (act) {
         const uint32_t pos = ea + __popcll(ba & lt);
+        const uint32_t g = eh + __popcll(bh & le) - 1;
         nslots[pos] = x;
         nvals[pos] = v;
-        const uint32_t g = eh + __popcll(bh & le) - 1;
         ngid[pos] = g;
+        ndep[pos] = nd;
         if (f) ghead[g] = pos;
       }
     }
@@ -259,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
 // as the reference's per-thread chunks do.  Needs the full-depth SA (rank is a permutation).
 template <typename SymT>
 __global__ __launch_bounds__(kBlock) void kasai_kernel(const SymT *__restrict__ sym, const uint32_t *__restrict__ sa,
-                                                       const uint32_t *__restrict__ rank, size_t n, size_t chunk,
+                                                       const RankEntry *__restrict__ rank, size_t n, size_t chunk,
                                                        int32_t *__restrict__ lcp) {
   const size_t c = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
   const size_t begin = c * chunk;
@@ -267,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void kasai_kernel(const SymT *__restrict__ 
   const size_t end = min(n, begin + chunk);
   size_t pl = 0;
   for (size_t i = begin; i < end; i++) {
-    const size_t r = rank[i];
+    const size_t r = rank_of(rank[i]);
     if (r + 1 != n) {
       const size_t j = sa[r + 1];
       const size_t mx = i > j ? i : j;

@@ -10,6 +10,7 @@
 // Tokens are emitted into a text-order array (one slot per code point) and stream-compacted.
 #pragma once
 #include "primitives.h"
+#include "suffix_array.h"
 
 namespace wp {
 
@@ -18,7 +19,7 @@ constexpr int32_t kNoEmit = static_cast<int32_t>(0x80808080u);  // hipMemset(0x8
 struct WalkArgs {
   const uint8_t *cls;
   size_t n_text;
-  const uint32_t *rank;
+  const RankEntry *rank;
   const int32_t *best_prefix, *best_suffix;
   const int32_t *tok_len;
   int32_t unk_id;
@@ -41,7 +42,7 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
   size_t since = p;  // start of the tokens counted by tokens_since_prefix
   while (p < end) {
     const bool prefix = w_word_prefix(a, p);
-    const uint32_t r = a.rank[p];
+    const uint32_t r = rank_of(a.rank[p]);
     const int32_t id = prefix ? a.best_prefix[r] : a.best_suffix[r];
     if (id != -1) {
       a.emit[p] = id;
