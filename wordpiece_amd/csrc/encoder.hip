@@ -98,7 +98,9 @@ struct Context {
     int sym_bytes = 0;
     const uint32_t *sa = nullptr, *cps = nullptr;
     const RankEntry *rank = nullptr;
-    const int32_t *lcp = nullptr, *bestp = nullptr, *bests = nullptr;
+    const int32_t *lcp = nullptr;
+    StepTable steps{};
+    int32_t *best_scratch = nullptr;  // room for 2n int32 (debug expansion of the step functions)
     size_t n = 0, n_text = 0;
   } dbg;
 };
@@ -274,12 +276,12 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
 
   const int M = static_cast<int>(hv.elig_id.size());
   const unsigned sl_tiles = cdiv(n, kSlTile);
-  const int D = static_cast<int>(std::min<int64_t>(hv.longest + hv.n_dup_eligible + 1, std::max(M, 1)));
-  const size_t carry_lds = (2 * static_cast<size_t>(D) + 2 * kCarryWin) * sizeof(int32_t);
-  if (carry_lds > 160 * 1024 - 1024) throw std::length_error("vocabulary nesting too deep for the scan kernel");
+  const int P = kStepsPerMark * M + 1;  // steps of the scanline result (scanline.h)
+  const int bucket_shift = std::max(0, bit_length(n) - 18);
+  const unsigned nbuckets = static_cast<unsigned>(((n - 1) >> bucket_shift) + 1);
 
   const size_t rr_tiles = cdiv(n, kRrTile);
-  const size_t radix_words = std::max(radix_tmp_words<uint64_t>(n), radix_tmp_words<uint32_t>(std::max(M, 1)));
+  const size_t radix_words = std::max(radix_tmp_words<uint64_t>(n), radix_tmp_words<uint32_t>(kStepsPerMark * std::max(M, 1) + 1));
   const size_t emit_tiles = cdiv(std::max<size_t>(n_text, 1), kScanTile);
 
   SymT *d_sym = nullptr;
@@ -288,16 +290,16 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   uint32_t *AD0 = nullptr, *AD1 = nullptr, *d_tdep = nullptr;
   uint32_t *V0 = nullptr, *V1 = nullptr, *AS0 = nullptr, *AS1 = nullptr, *AG = nullptr, *d_sa = nullptr,
            *d_radix_tmp = nullptr, *d_mslot0 = nullptr, *d_mslot1 = nullptr, *d_midx0 = nullptr,
-           *d_midx1 = nullptr, *d_minfo = nullptr, *d_tile_mlo = nullptr, *d_depth = nullptr, *d_emit_cnt = nullptr,
+           *d_midx1 = nullptr, *d_minfo = nullptr, *d_tile_mlo = nullptr, *d_emit_cnt = nullptr,
            *d_emit_tmp = nullptr;
-  int32_t *d_lcp = nullptr, *d_mid = nullptr, *d_interior = nullptr, *d_rf = nullptr, *d_rb = nullptr;
+  int32_t *d_lcp = nullptr, *d_mid = nullptr, *d_rf = nullptr, *d_rb = nullptr;
   RerankAgg *d_agg = nullptr;
   uint32_t *d_ghead = nullptr, *d_large_id = nullptr, *d_large_off = nullptr, *d_gscan_tmp = nullptr, *LV0 = nullptr,
            *LV1 = nullptr, *LPOS = nullptr;
   uint64_t *LK1 = nullptr;
-  int2 *d_pool = nullptr, *d_gsum_pool = nullptr, *d_gin_pool = nullptr;
-  uint32_t *d_gsum_depth = nullptr, *d_gin_depth = nullptr;
-  int32_t *d_lmin = nullptr, *d_gmin = nullptr;
+  int32_t *d_tmin_f = nullptr, *d_tmin_b = nullptr, *d_gmin_f = nullptr, *d_gmin_b = nullptr, *d_pval_p = nullptr,
+          *d_pval_s = nullptr;
+  uint32_t *d_ps0 = nullptr, *d_ps1 = nullptr, *d_pv0 = nullptr, *d_pv1 = nullptr, *d_bidx = nullptr;
   const unsigned sl_groups = cdiv(sl_tiles, kSlGroup);
   for (int pass = 0; pass < 2; pass++) {
     d_sym = ar.take<SymT>(n + 16);
@@ -333,15 +335,17 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     d_rf = ar.take<int32_t>(M + 1);
     d_rb = ar.take<int32_t>(M + 1);
     d_tile_mlo = ar.take<uint32_t>(sl_tiles + 2);
-    d_interior = ar.take<int32_t>(sl_tiles + 1);
-    d_depth = ar.take<uint32_t>(4 * static_cast<size_t>(sl_tiles));
-    d_pool = ar.take<int2>(4 * static_cast<size_t>(sl_tiles) * D);
-    d_lmin = ar.take<int32_t>(4 * static_cast<size_t>(sl_tiles));
-    d_gsum_pool = ar.take<int2>(4 * static_cast<size_t>(sl_groups) * D);
-    d_gin_pool = ar.take<int2>(4 * static_cast<size_t>(sl_groups) * D);
-    d_gsum_depth = ar.take<uint32_t>(4 * static_cast<size_t>(sl_groups));
-    d_gin_depth = ar.take<uint32_t>(4 * static_cast<size_t>(sl_groups));
-    d_gmin = ar.take<int32_t>(4 * static_cast<size_t>(sl_groups));
+    d_tmin_f = ar.take<int32_t>(sl_tiles + 1);
+    d_tmin_b = ar.take<int32_t>(sl_tiles + 1);
+    d_gmin_f = ar.take<int32_t>(sl_groups + 1);
+    d_gmin_b = ar.take<int32_t>(sl_groups + 1);
+    d_ps0 = ar.take<uint32_t>(P + 1);
+    d_ps1 = ar.take<uint32_t>(P + 1);
+    d_pv0 = ar.take<uint32_t>(P + 1);
+    d_pv1 = ar.take<uint32_t>(P + 1);
+    d_pval_p = ar.take<int32_t>(P + 1);
+    d_pval_s = ar.take<int32_t>(P + 1);
+    d_bidx = ar.take<uint32_t>(static_cast<size_t>(nbuckets) + 2);
     d_emit_cnt = ar.take<uint32_t>(emit_tiles + 1);
     d_emit_tmp = ar.take<uint32_t>(cdiv(emit_tiles, kScanTile) + 8);
     if (pass == 0) ar.commit();
@@ -476,7 +480,8 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[4], st));
 
   // ---------------- who marks + scanlines ----------------
-  int32_t *d_bestp = reinterpret_cast<int32_t *>(K0), *d_bests = reinterpret_cast<int32_t *>(K0) + n;
+  StepTable steps{};
+  MarkView mv{};
   {
     const size_t vocab_base = n_text + 1;
     uint32_t *mslot = d_mslot0, *midx = d_midx0;
@@ -493,22 +498,25 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     hipLaunchKernelGGL(tile_mlo_kernel, dim3(cdiv(sl_tiles + 1, kBlock)), dim3(kBlock), 0, st, mslot, M, n, sl_tiles,
                        d_tile_mlo);
     hipLaunchKernelGGL(sl_summary_kernel, dim3(sl_tiles), dim3(kBlock), 0, st, d_lcp, n, mslot, d_minfo, d_tile_mlo,
-                       d_interior, d_rf, d_rb);
-    if (carry_lds > 48 * 1024) {
-      WP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sl_carry_local_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(carry_lds)));
-      WP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sl_carry_group_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(carry_lds)));
+                       d_tmin_f, d_tmin_b, d_rf, d_rb);
+    hipLaunchKernelGGL(sl_group_min_kernel, dim3(cdiv(static_cast<size_t>(sl_groups) * kWave, kBlock)), dim3(kBlock),
+                       0, st, d_tmin_f, d_tmin_b, sl_tiles, sl_groups, d_gmin_f, d_gmin_b);
+    mv = MarkView{mslot, d_mid, d_minfo, d_rf, d_rb, M};
+    if (M > 0) {
+      hipLaunchKernelGGL(sl_reach_global_kernel, dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)), dim3(kBlock), 0,
+                         st, d_lcp, n, sl_tiles, sl_groups, mslot, d_minfo, M, d_tmin_f, d_tmin_b, d_gmin_f, d_gmin_b,
+                         d_rf, d_rb);
     }
-    hipLaunchKernelGGL(sl_carry_local_kernel, dim3(sl_groups, 4), dim3(kWave), carry_lds, st, d_lcp, n, sl_tiles,
-                       d_interior, d_tile_mlo, d_mid, d_minfo, M, D, d_pool, d_depth, d_lmin, sl_groups, d_gsum_pool,
-                       d_gsum_depth, d_gmin, c->d_scalars + 8);
-    hipLaunchKernelGGL(sl_carry_group_kernel, dim3(4), dim3(kWave), carry_lds, st, sl_groups, D, d_gsum_pool,
-                       d_gsum_depth, d_gmin, d_gin_pool, d_gin_depth, c->d_scalars + 8);
-    hipLaunchKernelGGL(sl_resolve_kernel, dim3(sl_tiles), dim3(kBlock), 0, st, d_lcp, n, sl_tiles, d_tile_mlo, mslot,
-                       d_mid, d_minfo, d_rf, d_rb, d_pool, d_depth, d_lmin, sl_groups, d_gin_pool, d_gin_depth, D,
-                       d_bestp, d_bests);
+    hipLaunchKernelGGL(piece_starts_kernel, dim3(cdiv(std::max(M, 1), kBlock)), dim3(kBlock), 0, st, mv, n, d_ps0);
+    const int pc = radix_sort_pairs<uint32_t>(d_ps0, d_pv0, d_ps1, d_pv1, P, 0, bit_length(n), d_radix_tmp, st,
+                                              nullptr);
+    uint32_t *pstart = pc ? d_ps1 : d_ps0;
+    hipLaunchKernelGGL(piece_values_kernel, dim3(cdiv(static_cast<size_t>(P) * kWave, kBlock)), dim3(kBlock), 0, st,
+                       mv, pstart, P, d_pval_p, d_pval_s);
+    hipLaunchKernelGGL(piece_bucket_kernel, dim3(cdiv(nbuckets + 1, kBlock)), dim3(kBlock), 0, st, pstart, P,
+                       bucket_shift, nbuckets, d_bidx);
     WP_LAUNCH_CHECK();
+    steps = StepTable{pstart, d_pval_p, d_pval_s, d_bidx, bucket_shift};
   }
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[5], st));
 
@@ -518,8 +526,9 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   size_t n_ids = 0;
   if (n_text > 0) {
     WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st));
-    WalkArgs wa{d_cls, n_text, d_rank, d_bestp, d_bests, c->d_tok_len, hv.unk_id, d_emit};
-    hipLaunchKernelGGL(walk_kernel, dim3(cdiv(cdiv(n_text, kWalkSpan), kBlock)), dim3(kBlock), 0, st, wa);
+    WalkArgs wa{d_cls, n_text, d_rank, steps, c->d_tok_len, hv.unk_id, d_emit};
+    static const int walk_span = getenv("WP_WALK_SPAN") ? std::max(1, atoi(getenv("WP_WALK_SPAN"))) : 8;
+    hipLaunchKernelGGL(walk_kernel, dim3(cdiv(cdiv(n_text, walk_span), kBlock)), dim3(kBlock), 0, st, wa, walk_span);
     const unsigned tiles = cdiv(n_text, kScanTile);
     hipLaunchKernelGGL(emit_count_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt);
     device_exclusive_scan(d_emit_cnt, d_emit_cnt, tiles, d_emit_tmp, c->d_scalars + 9, st);
@@ -528,7 +537,6 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   }
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[6], st));
   fetch_scalars(c, 10);
-  if (c->h_scalars[8]) throw std::length_error("scan stack overflow (vocabulary nesting deeper than expected)");
   n_ids = n_text > 0 ? c->h_scalars[9] : 0;
 
   S.n_ids = static_cast<int64_t>(n_ids);
@@ -554,8 +562,8 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   c->dbg.sa = d_sa;
   c->dbg.rank = d_rank;
   c->dbg.lcp = d_lcp;
-  c->dbg.bestp = d_bestp;
-  c->dbg.bests = d_bests;
+  c->dbg.steps = steps;
+  c->dbg.best_scratch = reinterpret_cast<int32_t *>(K0);  // K0 is free after the suffix sort
   c->dbg.cps = d_cps;
   c->dbg.n = n;
   c->dbg.n_text = n_text;
@@ -797,8 +805,15 @@ int wp_linear_debug_fetch(const wp_vocab *v, int which, int32_t *out, size_t cap
       case 1: src = d.sa; break;
       case 2: src = d.rank; break;
       case 3: src = d.lcp; cnt = d.n - 1; break;
-      case 4: src = d.bestp; break;
-      case 5: src = d.bests; break;
+      case 4:
+      case 5: {  // materialise the reference's per-slot arrays from the step functions
+        hipLaunchKernelGGL(step_expand_kernel, dim3(cdiv(d.n, kBlock)), dim3(kBlock), 0, c->stream, d.steps, d.n,
+                           d.best_scratch, d.best_scratch + d.n);
+        WP_LAUNCH_CHECK();
+        WP_HIP(hipStreamSynchronize(c->stream));
+        src = which == 4 ? d.best_scratch : d.best_scratch + d.n;
+        break;
+      }
       case 6: src = d.cps; cnt = d.n_text; break;
       default: throw std::invalid_argument("unknown debug array");
     }

@@ -10,6 +10,7 @@
 // Tokens are emitted into a text-order array (one slot per code point) and stream-compacted.
 #pragma once
 #include "primitives.h"
+#include "scanline.h"
 #include "suffix_array.h"
 
 namespace wp {
@@ -20,7 +21,7 @@ struct WalkArgs {
   const uint8_t *cls;
   size_t n_text;
   const RankEntry *rank;
-  const int32_t *best_prefix, *best_suffix;
+  StepTable steps;
   const int32_t *tok_len;
   int32_t unk_id;
   int32_t *emit;
@@ -43,7 +44,8 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
   while (p < end) {
     const bool prefix = w_word_prefix(a, p);
     const uint32_t r = rank_of(a.rank[p]);
-    const int32_t id = prefix ? a.best_prefix[r] : a.best_suffix[r];
+    const int k = step_lookup(a.steps, r);
+    const int32_t id = prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
     if (id != -1) {
       a.emit[p] = id;
       p += static_cast<size_t>(a.tok_len[id]);
@@ -68,12 +70,11 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
   }
 }
 
-// Each thread owns kWalkSpan consecutive positions and walks from every anchor among them (about one
+// Each thread owns `span` consecutive positions and walks from every anchor among them (about one
 // position in five is an anchor, so a thread-per-position launch would leave most lanes idle while
 // the few active ones wait on their dependent gathers).
-constexpr int kWalkSpan = 8;
-__global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a) {
-  const size_t p0 = (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) * kWalkSpan;
+__global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a, int span) {
+  const size_t p0 = (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) * span;
   if (p0 >= a.n_text) return;
   if (p0 == 0) {
     // the reference skips leading whitespace first (linear.cpp:227-229); if the first real
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a) {
     while (q < a.n_text && w_space(a, q)) ++q;
     if (q < a.n_text && q != 0 && !w_anchor(a, q)) walk_from(a, q);
   }
-  const size_t p1 = min(a.n_text, p0 + kWalkSpan);
+  const size_t p1 = min(a.n_text, p0 + span);
   uint8_t prev = p0 > 0 ? a.cls[p0 - 1] : 0;
   for (size_t p = p0; p < p1; p++) {
     const uint8_t c = a.cls[p];
