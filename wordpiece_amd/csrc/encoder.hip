@@ -526,9 +526,18 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   size_t n_ids = 0;
   if (n_text > 0) {
     WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st));
-    WalkArgs wa{d_cls, n_text, d_rank, steps, c->d_tok_len, hv.unk_id, d_emit};
-    static const int walk_span = getenv("WP_WALK_SPAN") ? std::max(1, atoi(getenv("WP_WALK_SPAN"))) : 8;
-    hipLaunchKernelGGL(walk_kernel, dim3(cdiv(cdiv(n_text, walk_span), kBlock)), dim3(kBlock), 0, st, wa, walk_span);
+    static const int walk_dbg = getenv("WP_WALK_DBG") ? atoi(getenv("WP_WALK_DBG")) : 0;
+    WalkArgs wa{d_cls, n_text, d_rank, steps, c->d_tok_len, hv.unk_id, d_emit, walk_dbg};
+    // anchors -> list (count, scan, write), then one lane per anchor.  The anchor count stays on the
+    // device; the walk grid is sized for the worst case (every position an anchor) only when small,
+    // otherwise for one anchor per two positions, which text cannot exceed... so use n_text.
+    const unsigned atiles = cdiv(n_text, kScanTile);
+    uint32_t *d_anchors = reinterpret_cast<uint32_t *>(K1);  // K1 is free after the suffix sort (8n bytes)
+    hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, n_text, d_emit_cnt);
+    device_exclusive_scan(d_emit_cnt, d_emit_cnt, atiles, d_emit_tmp, c->d_scalars + 10, st);
+    hipLaunchKernelGGL(anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, n_text, d_emit_cnt, d_anchors);
+    hipLaunchKernelGGL(walk_kernel, dim3(cdiv(n_text, kBlock)), dim3(kBlock), 0, st, wa, d_anchors,
+                       c->d_scalars + 10, n_text);
     const unsigned tiles = cdiv(n_text, kScanTile);
     hipLaunchKernelGGL(emit_count_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt);
     device_exclusive_scan(d_emit_cnt, d_emit_cnt, tiles, d_emit_tmp, c->d_scalars + 9, st);

@@ -25,6 +25,7 @@ struct WalkArgs {
   const int32_t *tok_len;
   int32_t unk_id;
   int32_t *emit;
+  int dbg;  // timing experiments only (WP_WALK_DBG): 1 = no emit stores, 2 = no step lookup, 4 = no rank load
 };
 
 __device__ __forceinline__ bool w_space(const WalkArgs &a, size_t p) { return a.cls[p] & kClsSpace; }
@@ -43,11 +44,11 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
   size_t since = p;  // start of the tokens counted by tokens_since_prefix
   while (p < end) {
     const bool prefix = w_word_prefix(a, p);
-    const uint32_t r = rank_of(a.rank[p]);
-    const int k = step_lookup(a.steps, r);
-    const int32_t id = prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
+    const uint32_t r = (a.dbg & 4) ? static_cast<uint32_t>(p) : rank_of(a.rank[p]);
+    const int k = (a.dbg & 2) ? 0 : step_lookup(a.steps, r);
+    const int32_t id = (a.dbg & 2) ? static_cast<int32_t>(5 + (r & 63)) : (prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k]);
     if (id != -1) {
-      a.emit[p] = id;
+      if (!(a.dbg & 1)) a.emit[p] = id;
       p += static_cast<size_t>(a.tok_len[id]);
       if (p < end && w_word_prefix(a, p)) since = p;
     } else {
@@ -70,27 +71,70 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
   }
 }
 
-// Each thread owns `span` consecutive positions and walks from every anchor among them (about one
-// position in five is an anchor, so a thread-per-position launch would leave most lanes idle while
-// the few active ones wait on their dependent gathers).
-__global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a, int span) {
-  const size_t p0 = (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) * span;
-  if (p0 >= a.n_text) return;
-  if (p0 == 0) {
+// The walk is latency bound (about six dependent loads per token), and only one text position in
+// five is an anchor, so anchors are first compacted into a list: every lane of the walk kernel
+// then owns one anchor (= one word) and the waves are dense.
+__device__ __forceinline__ bool anchor_at(const uint8_t *__restrict__ cls, size_t p) {
+  const uint8_t c = cls[p];
+  if (c & kClsSpace) return false;
+  return p == 0 || w_hard(c) || w_hard(cls[p - 1]);
+}
+
+__global__ __launch_bounds__(kBlock) void anchor_count_kernel(const uint8_t *__restrict__ cls, size_t n,
+                                                              uint32_t *__restrict__ tile_counts) {
+  __shared__ uint32_t sm[8];
+  const size_t base = static_cast<size_t>(blockIdx.x) * kScanTile;
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; j++) {
+    const size_t i = base + static_cast<size_t>(j) * kBlock + threadIdx.x;
+    if (i < n && anchor_at(cls, i)) c++;
+  }
+  uint32_t tot;
+  (void)block_excl_sum(c, sm, tot);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
+}
+
+// wave-striped so that the list stays in text order and the stores are coalesced
+__global__ __launch_bounds__(kBlock) void anchor_write_kernel(const uint8_t *__restrict__ cls, size_t n,
+                                                              const uint32_t *__restrict__ tile_prefix,
+                                                              uint32_t *__restrict__ anchors) {
+  __shared__ uint32_t wtot[4];
+  const int lane = lane_id(), w = wave_id();
+  const size_t wave_base = static_cast<size_t>(blockIdx.x) * kScanTile + static_cast<size_t>(w) * (kScanTile / 4);
+  uint64_t bal[kScanItems];
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int r = 0; r < kScanItems; r++) {
+    const size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
+    bal[r] = __ballot(i < n && anchor_at(cls, i));
+    cnt += __popcll(bal[r]);
+  }
+  if (lane == 0) wtot[w] = cnt;
+  __syncthreads();
+  uint32_t o = tile_prefix[blockIdx.x];
+  for (int i = 0; i < w; i++) o += wtot[i];
+  const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < kScanItems; r++) {
+    const size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
+    if ((bal[r] >> lane) & 1ull) anchors[o + __popcll(bal[r] & lt)] = static_cast<uint32_t>(i);
+    o += __popcll(bal[r]);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a, const uint32_t *__restrict__ anchors,
+                                                      const uint32_t *__restrict__ n_anchors_dev, size_t cap) {
+  const size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k == 0) {
     // the reference skips leading whitespace first (linear.cpp:227-229); if the first real
     // position is not an anchor by itself, this thread owns it
     size_t q = 0;
     while (q < a.n_text && w_space(a, q)) ++q;
     if (q < a.n_text && q != 0 && !w_anchor(a, q)) walk_from(a, q);
   }
-  const size_t p1 = min(a.n_text, p0 + span);
-  uint8_t prev = p0 > 0 ? a.cls[p0 - 1] : 0;
-  for (size_t p = p0; p < p1; p++) {
-    const uint8_t c = a.cls[p];
-    const bool anchor = !(c & kClsSpace) && (p == 0 || w_hard(c) || w_hard(prev));
-    prev = c;
-    if (anchor) walk_from(a, p);
-  }
+  if (k >= cap || k >= *n_anchors_dev) return;
+  walk_from(a, anchors[k]);
 }
 
 // ---- compaction of emit[] into the id stream ----------------------------------------------------
