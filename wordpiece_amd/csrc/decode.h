@@ -43,14 +43,22 @@ __global__ __launch_bounds__(kBlock) void decode_count_kernel(const uint8_t *__r
   if (off < nbytes) {
     uint8_t b[20];
     load_bytes20(text, nbytes, off, b);
+    bool ascii = off + kDecBytes <= nbytes;
 #pragma unroll
-    for (int j = 0; j < kDecBytes; j++) {
-      if (off + j < nbytes) {
-        if ((b[j] & 0xc0u) != 0x80u) {
-          uint32_t cp = decode_one(&b[j], static_cast<int64_t>(nbytes - (off + j)));
-          if (cp != kInvalidUnicode) {
-            cnt++;
-            used_bytes += cp < 0x80 ? 1 : cp < 0x800 ? 2 : cp < 0x10000 ? 3 : 4;
+    for (int j = 0; j < kDecBytes; j++) ascii = ascii && b[j] < 0x80;
+    if (ascii) {  // common case: 16 one-byte code points
+      cnt = kDecBytes;
+      used_bytes = kDecBytes;
+    } else {
+#pragma unroll
+      for (int j = 0; j < kDecBytes; j++) {
+        if (off + j < nbytes) {
+          if ((b[j] & 0xc0u) != 0x80u) {
+            uint32_t cp = decode_one(&b[j], static_cast<int64_t>(nbytes - (off + j)));
+            if (cp != kInvalidUnicode) {
+              cnt++;
+              used_bytes += cp < 0x80 ? 1 : cp < 0x800 ? 2 : cp < 0x10000 ? 3 : 4;
+            }
           }
         }
       }
@@ -80,12 +88,21 @@ __global__ __launch_bounds__(kBlock) void decode_write_kernel(
   if (off < nbytes) {
     uint8_t b[20];
     load_bytes20(text, nbytes, off, b);
+    bool ascii = off + kDecBytes <= nbytes;
 #pragma unroll
-    for (int j = 0; j < kDecBytes; j++) {
-      cp[j] = kInvalidUnicode;
-      if (off + j < nbytes && (b[j] & 0xc0u) != 0x80u) {
-        cp[j] = decode_one(&b[j], static_cast<int64_t>(nbytes - (off + j)));
-        if (cp[j] != kInvalidUnicode) cnt++;
+    for (int j = 0; j < kDecBytes; j++) ascii = ascii && b[j] < 0x80;
+    if (ascii) {
+#pragma unroll
+      for (int j = 0; j < kDecBytes; j++) cp[j] = b[j];
+      cnt = kDecBytes;
+    } else {
+#pragma unroll
+      for (int j = 0; j < kDecBytes; j++) {
+        cp[j] = kInvalidUnicode;
+        if (off + j < nbytes && (b[j] & 0xc0u) != 0x80u) {
+          cp[j] = decode_one(&b[j], static_cast<int64_t>(nbytes - (off + j)));
+          if (cp[j] != kInvalidUnicode) cnt++;
+        }
       }
     }
   } else {

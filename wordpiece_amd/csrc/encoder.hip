@@ -287,7 +287,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   SymT *d_sym = nullptr;
   uint64_t *K0 = nullptr, *K1 = nullptr;
   RankEntry *d_rank = nullptr;
-  uint32_t *AD0 = nullptr, *AD1 = nullptr, *d_tdep = nullptr;
+  uint32_t *AD0 = nullptr, *AD1 = nullptr, *d_tdep = nullptr, *d_gdepth = nullptr;
   uint32_t *V0 = nullptr, *V1 = nullptr, *AS0 = nullptr, *AS1 = nullptr, *AG = nullptr, *d_sa = nullptr,
            *d_radix_tmp = nullptr, *d_mslot0 = nullptr, *d_mslot1 = nullptr, *d_midx0 = nullptr,
            *d_midx1 = nullptr, *d_minfo = nullptr, *d_tile_mlo = nullptr, *d_emit_cnt = nullptr,
@@ -297,6 +297,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   uint32_t *d_ghead = nullptr, *d_large_id = nullptr, *d_large_off = nullptr, *d_gscan_tmp = nullptr, *LV0 = nullptr,
            *LV1 = nullptr, *LPOS = nullptr;
   uint64_t *LK1 = nullptr;
+  int32_t *d_cover_f = nullptr, *d_cover_b = nullptr;
   int32_t *d_tmin_f = nullptr, *d_tmin_b = nullptr, *d_gmin_f = nullptr, *d_gmin_b = nullptr, *d_pval_p = nullptr,
           *d_pval_s = nullptr;
   uint32_t *d_ps0 = nullptr, *d_ps1 = nullptr, *d_pv0 = nullptr, *d_pv1 = nullptr, *d_bidx = nullptr;
@@ -315,6 +316,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     AD0 = ar.take<uint32_t>(n);
     AD1 = ar.take<uint32_t>(n);
     d_tdep = ar.take<uint32_t>(n);
+    d_gdepth = ar.take<uint32_t>(n);
     d_lcp = ar.take<int32_t>(n);
     d_radix_tmp = ar.take<uint32_t>(radix_words);
     d_ghead = ar.take<uint32_t>(n / 2 + 4);
@@ -333,6 +335,8 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     d_mid = ar.take<int32_t>(M + 1);
     d_minfo = ar.take<uint32_t>(M + 1);
     d_rf = ar.take<int32_t>(M + 1);
+    d_cover_f = ar.take<int32_t>(2 * static_cast<size_t>(M) + 2);
+    d_cover_b = ar.take<int32_t>(2 * static_cast<size_t>(M) + 2);
     d_rb = ar.take<int32_t>(M + 1);
     d_tile_mlo = ar.take<uint32_t>(sl_tiles + 2);
     d_tmin_f = ar.take<int32_t>(sl_tiles + 1);
@@ -404,15 +408,16 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   {
     const unsigned tiles = cdiv(n, kRrTile);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<true>), dim3(tiles), dim3(kBlock), 0, st, keys, vals, n,
-                       static_cast<const uint32_t *>(nullptr), static_cast<const RankEntry *>(nullptr), n,
-                       dcode.first_len, dcode.uniform_bits, rule, d_tdep, d_agg);
+                       static_cast<const uint32_t *>(nullptr), static_cast<const RankEntry *>(nullptr),
+                       static_cast<const uint32_t *>(nullptr), n, dcode.first_len, dcode.uniform_bits, rule, d_tdep,
+                       d_agg);
     hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kBlock), 0, st, d_agg, static_cast<size_t>(tiles),
                        c->d_scalars + 4, d_ghead);
     RankEntry *hd = reinterpret_cast<RankEntry *>(cur ? K0 : K1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
                        vals, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), d_tdep, n,
                        d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp, slots, other_vals,
-                       AG, adep, d_ghead);
+                       AG, adep, d_ghead, d_gdepth);
     hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, vals, hd, n, d_rank);
     WP_LAUNCH_CHECK();
     classify_groups(n);
@@ -444,13 +449,13 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
     }
     const unsigned tiles = cdiv(n_act, kRrTile);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<false>), dim3(tiles), dim3(kBlock), 0, st, skeys, svals,
-                       n_act, adep, d_rank, n, dcode.first_len, dcode.uniform_bits, rule, d_tdep, d_agg);
+                       n_act, adep, d_rank, d_gdepth, n, dcode.first_len, dcode.uniform_bits, rule, d_tdep, d_agg);
     hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kBlock), 0, st, d_agg, static_cast<size_t>(tiles),
                        c->d_scalars + 4, d_ghead);
     RankEntry *hd = reinterpret_cast<RankEntry *>(kfree);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
                        svals, slots, adep, d_tdep, n_act, d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule,
-                       d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead);
+                       d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead, d_gdepth);
     hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, svals, hd, n_act,
                        d_rank);
     WP_LAUNCH_CHECK();
@@ -501,11 +506,15 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
                        d_tmin_f, d_tmin_b, d_rf, d_rb);
     hipLaunchKernelGGL(sl_group_min_kernel, dim3(cdiv(static_cast<size_t>(sl_groups) * kWave, kBlock)), dim3(kBlock),
                        0, st, d_tmin_f, d_tmin_b, sl_tiles, sl_groups, d_gmin_f, d_gmin_b);
-    mv = MarkView{mslot, d_mid, d_minfo, d_rf, d_rb, M};
+    mv = MarkView{mslot, d_mid, d_minfo, d_rf, d_rb, M, d_cover_f, d_cover_b};
     if (M > 0) {
       hipLaunchKernelGGL(sl_reach_global_kernel, dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)), dim3(kBlock), 0,
                          st, d_lcp, n, sl_tiles, sl_groups, mslot, d_minfo, M, d_tmin_f, d_tmin_b, d_gmin_f, d_gmin_b,
                          d_rf, d_rb);
+    }
+    if (M > 0) {
+      hipLaunchKernelGGL(mark_cover_kernel, dim3(1), dim3(kBlock), 0, st, d_minfo, d_rf, d_rb, M, d_cover_f,
+                         d_cover_b);
     }
     hipLaunchKernelGGL(piece_starts_kernel, dim3(cdiv(std::max(M, 1), kBlock)), dim3(kBlock), 0, st, mv, n, d_ps0);
     const int pc = radix_sort_pairs<uint32_t>(d_ps0, d_pv0, d_ps1, d_pv1, P, 0, bit_length(n), d_radix_tmp, st,
@@ -829,11 +838,7 @@ int wp_linear_debug_fetch(const wp_vocab *v, int which, int32_t *out, size_t cap
     if (cnt > capacity) throw std::invalid_argument("debug buffer too small");
     *n_out = cnt;
     if (cnt == 0) return;
-    if (which == 2) {
-      std::vector<RankEntry> tmp(cnt);
-      WP_HIP(hipMemcpy(tmp.data(), src, cnt * sizeof(RankEntry), hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < cnt; i++) out[i] = static_cast<int32_t>(rank_of(tmp[i]));
-    } else if (which == 0 && d.sym_bytes == 1) {
+    if (which == 0 && d.sym_bytes == 1) {
       std::vector<uint8_t> tmp(cnt);
       WP_HIP(hipMemcpy(tmp.data(), src, cnt, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < cnt; i++) out[i] = tmp[i];

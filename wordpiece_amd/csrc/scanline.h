@@ -247,7 +247,46 @@ struct MarkView {
   const uint32_t *minfo;
   const int32_t *reach_fwd, *reach_bwd;
   int M;
+  // per class c: cover_f[c*M + q] = max reach_fwd over marks <= q of class c (no mark at or before q
+  // covers slot j when it is <= j); cover_b[c*M + q] = min reach_bwd over marks >= q of class c
+  const int32_t *cover_f, *cover_b;
 };
+
+// single workgroup: running max / min per class over the (sorted) marks
+__global__ __launch_bounds__(kBlock) void mark_cover_kernel(const uint32_t *__restrict__ minfo,
+                                                            const int32_t *__restrict__ reach_fwd,
+                                                            const int32_t *__restrict__ reach_bwd, int M,
+                                                            int32_t *__restrict__ cover_f, int32_t *__restrict__ cover_b) {
+  __shared__ int32_t smx[8];
+  __shared__ int32_t carry[2];
+  const int tid = threadIdx.x;
+  for (int c = 0; c < 2; c++) {
+    if (tid == 0) carry[0] = -2147483647 - 1;
+    __syncthreads();
+    for (int base = 0; base < M; base += kBlock) {  // forward running max
+      const int q = base + tid;
+      int32_t v = -2147483647 - 1;
+      if (q < M && static_cast<int>(minfo[q] >> kMarkClsShift) == c) v = reach_fwd[q];
+      const int32_t inc = max(block_incl_max(v, smx), carry[0]);
+      if (q < M) cover_f[static_cast<size_t>(c) * M + q] = inc;
+      __syncthreads();
+      if (tid == kBlock - 1) carry[0] = inc;
+      __syncthreads();
+    }
+    if (tid == 0) carry[1] = -2147483647 - 1;  // backward running min as a max of negated values
+    __syncthreads();
+    for (int base = 0; base < M; base += kBlock) {
+      const int q = M - 1 - (base + tid);
+      int32_t v = -2147483647 - 1;
+      if (q >= 0 && static_cast<int>(minfo[q] >> kMarkClsShift) == c) v = -reach_bwd[q] - 1;
+      const int32_t inc = max(block_incl_max(v, smx), carry[1]);
+      if (q >= 0) cover_b[static_cast<size_t>(c) * M + q] = inc == (-2147483647 - 1) ? 2147483647 : -(inc + 1);
+      __syncthreads();
+      if (tid == kBlock - 1) carry[1] = inc;
+      __syncthreads();
+    }
+  }
+}
 
 // step starts: slot 0 and, per mark, {first covered slot, own slot, the slot after it, first slot
 // past its reach}.  (For duplicate-free vocabularies the first and last alone would do; the own
@@ -283,7 +322,13 @@ __global__ __launch_bounds__(kBlock) void piece_values_kernel(MarkView mv, const
   }
   const int ub = lo;
   int xq[2] = {-1, -1}, yq[2] = {-1, -1};  // mark index of the stack tops per class
-  for (int top = ub - 1; top >= 0 && (xq[0] < 0 || xq[1] < 0); top -= kWave) {
+  bool fdone[2] = {false, false}, bdone[2] = {false, false};  // class finished: found, or nothing can cover
+  for (int top = ub - 1; top >= 0; top -= kWave) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      if (xq[c] >= 0 || mv.cover_f[static_cast<size_t>(c) * mv.M + top] <= static_cast<int32_t>(slot)) fdone[c] = true;
+    }
+    if (fdone[0] && fdone[1]) break;
     const int q = top - lane;
     bool cover = false;
     int cls = 0;
@@ -300,7 +345,12 @@ __global__ __launch_bounds__(kBlock) void piece_values_kernel(MarkView mv, const
   }
   int lb = ub;
   if (ub > 0 && mv.mslot[ub - 1] == slot) lb = ub - 1;  // a mark on this very slot counts for both scans
-  for (int base = lb; base < mv.M && (yq[0] < 0 || yq[1] < 0); base += kWave) {
+  for (int base = lb; base < mv.M; base += kWave) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      if (yq[c] >= 0 || mv.cover_b[static_cast<size_t>(c) * mv.M + base] >= static_cast<int32_t>(slot)) bdone[c] = true;
+    }
+    if (bdone[0] && bdone[1]) break;
     const int q = base + lane;
     bool cover = false;
     int cls = 0;

@@ -22,12 +22,11 @@ namespace wp {
 constexpr int kRrItems = 8;
 constexpr int kRrTile = kBlock * kRrItems;  // 2048 list entries per workgroup
 
-// rank table entry of a text position: low word = rank (first SA slot of its group), high word =
-// the group's depth (symbols its members are known to share; meaningful for tied groups only)
-using RankEntry = uint64_t;
-__host__ __device__ inline uint32_t rank_of(RankEntry e) { return static_cast<uint32_t>(e); }
-__host__ __device__ inline uint32_t depth_of(RankEntry e) { return static_cast<uint32_t>(e >> 32); }
-constexpr uint64_t kRankUnchanged = ~0ull;
+// rank[i] = first SA slot of i's group.  The depth of a tied group (symbols its members are known
+// to share) is kept per group at gdepth[first slot of the group].
+using RankEntry = uint32_t;
+__host__ __device__ inline uint32_t rank_of(RankEntry e) { return e; }
+constexpr uint32_t kRankUnchanged = 0xffffffffu;  // never a rank: ranks are < n <= 2e9
 
 struct RerankAgg {
   uint32_t last_flag;  // 1 + largest k in the tile that starts a group, 0 if none
@@ -60,7 +59,8 @@ template <bool ROUND0>
 __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__restrict__ keys,
                                                             const uint32_t *__restrict__ vals, size_t m,
                                                             const uint32_t *__restrict__ adep,
-                                                            const RankEntry *__restrict__ rd, size_t n,
+                                                            const RankEntry *__restrict__ rd,
+                                                            const uint32_t *__restrict__ gdepth, size_t n,
                                                             const uint8_t *__restrict__ first_len, int uniform_bits,
                                                             DepthRule rule, uint32_t *__restrict__ tdep,
                                                             RerankAgg *__restrict__ agg) {
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
         } else {
           const uint32_t d = adep[k];
           const size_t t = static_cast<size_t>(vals[k]) + d;
-          const uint32_t dj = t < n ? depth_of(rd[t]) : 0u;
+          const uint32_t dj = t < n ? gdepth[rd[t]] : 0u;
           nd = min(d + dj, 0x7fffffffu);
         }
         tdep[k] = nd;
@@ -204,7 +204,8 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     const RerankAgg *__restrict__ agg, const SymT *__restrict__ sym, size_t n, const uint8_t *__restrict__ first_len,
     int uniform_bits, DepthRule rule, uint32_t *__restrict__ sa, RankEntry *__restrict__ hd,
     int32_t *__restrict__ lcp, uint32_t *__restrict__ nslots, uint32_t *__restrict__ nvals,
-    uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep, uint32_t *__restrict__ ghead) {
+    uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep, uint32_t *__restrict__ ghead,
+    uint32_t *__restrict__ gdepth) {
   __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
   __shared__ uint8_t s_fl[1 << 12];
   if (ROUND0 && !uniform_bits) {
@@ -267,7 +268,8 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
       bool changed = true;
       if (!ROUND0) changed = head > 0 && (keys[head] >> 32) == (keys[head - 1] >> 32);
       const uint32_t nd = single ? 0u : tdep[k];
-      hd[k] = changed ? ((static_cast<uint64_t>(nd) << 32) | head_slot) : kRankUnchanged;
+      hd[k] = changed ? head_slot : kRankUnchanged;
+      if (f && !single) gdepth[x] = nd;  // x is the first slot of this (still tied) group
       if (ROUND0) {
         if (k > 0) {
           int32_t l = -1;
