@@ -41,6 +41,7 @@ def check_all_stages(text, vocab, label=""):
     d = ov.encode_debug(text)
     gv = W.Vocab(vocab)
     gv.set_option(W.WP_OPT_FULL_DEPTH, 1)
+    gv.set_option(W.WP_OPT_KEEP_DEBUG, 1)  # keeps the raw code points for debug_fetch(6)
     ids = gv.encode(text)
     n = d["n"]
     if len(text) and d["n_text"] > 0:

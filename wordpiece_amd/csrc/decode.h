@@ -36,8 +36,12 @@ __device__ __forceinline__ void load_bytes20(const uint8_t *__restrict__ text, s
 // (consumed != nbytes  <=>  the reference would print its invalid-unicode warning, utf8.cpp:143-145)
 __global__ __launch_bounds__(kBlock) void decode_count_kernel(const uint8_t *__restrict__ text, size_t nbytes,
                                                               uint32_t *__restrict__ tile_counts,
-                                                              unsigned long long *__restrict__ consumed) {
+                                                              unsigned long long *__restrict__ consumed,
+                                                              uint32_t *__restrict__ used) {
   __shared__ uint32_t sm[8];
+  __shared__ uint32_t low_used[8];  // bitmap of code points < 256 seen by this tile
+  if (threadIdx.x < 8) low_used[threadIdx.x] = 0;
+  __syncthreads();
   const size_t off = static_cast<size_t>(blockIdx.x) * kDecTile + static_cast<size_t>(threadIdx.x) * kDecBytes;
   uint32_t cnt = 0, used_bytes = 0;
   if (off < nbytes) {
@@ -49,6 +53,20 @@ __global__ __launch_bounds__(kBlock) void decode_count_kernel(const uint8_t *__r
     if (ascii) {  // common case: 16 one-byte code points
       cnt = kDecBytes;
       used_bytes = kDecBytes;
+      uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;  // bits of the 128-entry ASCII part of the bitmap
+#pragma unroll
+      for (int j = 0; j < kDecBytes; j++) {
+        const uint32_t bit = 1u << (b[j] & 31);
+        const int wi = b[j] >> 5;
+        m0 |= wi == 0 ? bit : 0u;
+        m1 |= wi == 1 ? bit : 0u;
+        m2 |= wi == 2 ? bit : 0u;
+        m3 |= wi == 3 ? bit : 0u;
+      }
+      if (m0 & ~low_used[0]) atomicOr(&low_used[0], m0);
+      if (m1 & ~low_used[1]) atomicOr(&low_used[1], m1);
+      if (m2 & ~low_used[2]) atomicOr(&low_used[2], m2);
+      if (m3 & ~low_used[3]) atomicOr(&low_used[3], m3);
     } else {
 #pragma unroll
       for (int j = 0; j < kDecBytes; j++) {
@@ -58,6 +76,11 @@ __global__ __launch_bounds__(kBlock) void decode_count_kernel(const uint8_t *__r
             if (cp != kInvalidUnicode) {
               cnt++;
               used_bytes += cp < 0x80 ? 1 : cp < 0x800 ? 2 : cp < 0x10000 ? 3 : 4;
+              if (cp < 256) {
+                atomicOr(&low_used[cp >> 5], 1u << (cp & 31));
+              } else {
+                used[cp] = 1u;
+              }
             }
           }
         }
@@ -71,17 +94,20 @@ __global__ __launch_bounds__(kBlock) void decode_count_kernel(const uint8_t *__r
     tile_counts[blockIdx.x] = tot;
     atomicAdd(consumed, static_cast<unsigned long long>(tot_bytes));
   }
+  if ((low_used[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1u) used[threadIdx.x] = 1u;
 }
 
-// pass 2: write code points, class bytes and mark used code points
+// pass 2 (after the alphabet is known): dense symbols, class bytes, symbol histogram; the raw code
+// points are only kept when a debug copy is requested
+template <typename SymT>
 __global__ __launch_bounds__(kBlock) void decode_write_kernel(
     const uint8_t *__restrict__ text, size_t nbytes, const uint32_t *__restrict__ tile_prefix,
-    uint32_t *__restrict__ cps, uint8_t *__restrict__ cls, uint32_t *__restrict__ used,
-    const uint32_t *__restrict__ soft, int nsoft) {
+    const uint32_t *__restrict__ lut_excl, SymT *__restrict__ sym, uint8_t *__restrict__ cls,
+    uint32_t *__restrict__ cps_dbg, const uint32_t *__restrict__ soft, int nsoft, uint32_t *__restrict__ sym_hist) {
   __shared__ uint32_t sm[8];
   __shared__ uint32_t scp[kDecTile];
-  __shared__ uint32_t low_used[8];  // bitmap of code points < 256 seen by this tile
-  if (threadIdx.x < 8) low_used[threadIdx.x] = 0;
+  __shared__ uint32_t shist[256];
+  if (sizeof(SymT) == 1) shist[threadIdx.x] = 0;
   const size_t off = static_cast<size_t>(blockIdx.x) * kDecTile + static_cast<size_t>(threadIdx.x) * kDecBytes;
   uint32_t cp[kDecBytes];
   uint32_t cnt = 0;
@@ -113,20 +139,16 @@ __global__ __launch_bounds__(kBlock) void decode_write_kernel(
   uint32_t pos = block_excl_sum(cnt, sm, tot);
 #pragma unroll
   for (int j = 0; j < kDecBytes; j++) {
-    if (cp[j] != kInvalidUnicode) {
-      scp[pos++] = cp[j];
-      if (cp[j] < 256) {
-        atomicOr(&low_used[cp[j] >> 5], 1u << (cp[j] & 31));
-      } else {
-        used[cp[j]] = 1u;
-      }
-    }
+    if (cp[j] != kInvalidUnicode) scp[pos++] = cp[j];
   }
   __syncthreads();
   const size_t out_base = tile_prefix[blockIdx.x];
   for (uint32_t k = threadIdx.x; k < tot; k += kBlock) {
     const uint32_t c = scp[k];
-    cps[out_base + k] = c;
+    const uint32_t sv = lut_excl[c] + 1u;
+    sym[out_base + k] = static_cast<SymT>(sv);
+    if (sizeof(SymT) == 1) atomicAdd(&shist[sv & 255u], 1u);
+    if (cps_dbg) cps_dbg[out_base + k] = c;
     uint8_t f = 0;
     if (is_space(c)) f |= kClsSpace;
     if (is_spacing_char(c)) {
@@ -140,7 +162,10 @@ __global__ __launch_bounds__(kBlock) void decode_write_kernel(
     }
     cls[out_base + k] = f;
   }
-  if ((low_used[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1u) used[threadIdx.x] = 1u;
+  if (sizeof(SymT) == 1) {
+    __syncthreads();
+    if (shist[threadIdx.x]) atomicAdd(&sym_hist[threadIdx.x], shist[threadIdx.x]);
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void mark_used_kernel(const uint32_t *__restrict__ cps, size_t n,
@@ -150,31 +175,20 @@ __global__ __launch_bounds__(kBlock) void mark_used_kernel(const uint32_t *__res
   if (i == 0) used[1] = 1u;  // the separator (linear.cpp:92,99)
 }
 
-// sym[i] = dense, order-preserving symbol id (>= 1; 0 is reserved for "past the end")
+// the separator and the vocab stream behind the text: sym[n_text + k] (dense, order-preserving
+// symbol id >= 1; 0 is reserved for "past the end"), plus their share of the symbol histogram
 template <typename SymT>
-__global__ __launch_bounds__(kBlock) void map_symbols_kernel(const uint32_t *__restrict__ cps, size_t n_text,
-                                                             const uint32_t *__restrict__ vocab_cps, size_t n,
-                                                             const uint32_t *__restrict__ lut_excl,
-                                                             SymT *__restrict__ sym) {
-  size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+__global__ __launch_bounds__(kBlock) void map_vocab_symbols_kernel(const uint32_t *__restrict__ vocab_cps,
+                                                                   size_t n_text, size_t n,
+                                                                   const uint32_t *__restrict__ lut_excl,
+                                                                   SymT *__restrict__ sym,
+                                                                   uint32_t *__restrict__ sym_hist) {
+  size_t i = n_text + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
-  uint32_t c = i < n_text ? cps[i] : (i == n_text ? 1u : vocab_cps[i - n_text - 1]);
-  sym[i] = static_cast<SymT>(lut_excl[c] + 1u);
-}
-
-// symbol histogram (8-bit symbol path): feeds the host-side code construction (code.h)
-__global__ __launch_bounds__(kBlock) void sym_hist_kernel(const uint8_t *__restrict__ sym, size_t n,
-                                                          uint32_t *__restrict__ hist) {
-  __shared__ uint32_t sh[256];
-  sh[threadIdx.x] = 0;
-  __syncthreads();
-  const size_t base = static_cast<size_t>(blockIdx.x) * (kBlock * 64);
-  for (int j = 0; j < 64; j++) {
-    const size_t i = base + static_cast<size_t>(j) * kBlock + threadIdx.x;
-    if (i < n) atomicAdd(&sh[sym[i]], 1u);
-  }
-  __syncthreads();
-  if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+  const uint32_t c = i == n_text ? 1u : vocab_cps[i - n_text - 1];
+  const uint32_t sv = lut_excl[c] + 1u;
+  sym[i] = static_cast<SymT>(sv);
+  if (sizeof(SymT) == 1) atomicAdd(&sym_hist[sv & 255u], 1u);
 }
 
 // Device copy of the symbol code (code.h).  uniform_bits > 0: fixed width, tables unused.

@@ -193,8 +193,9 @@ static void fetch_scalars(Context *c, int count) {
 }
 
 template <typename SymT>
-static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text, size_t n, const uint32_t *d_cps,
-                              const uint8_t *d_cls, int bits, size_t *n_ids_out);
+static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t *d_text, size_t nbytes,
+                              const uint32_t *d_tile_prefix, size_t n_text, size_t n, uint32_t *d_cps, uint8_t *d_cls,
+                              int bits, size_t *n_ids_out);
 
 // The whole device path.  d_text must be 4-byte aligned and readable up to the next multiple of 4.
 static void encode_on_device(wp_vocab *v, const uint8_t *d_text, size_t nbytes, size_t *n_ids_out) {
@@ -225,17 +226,15 @@ static void encode_on_device(wp_vocab *v, const uint8_t *d_text, size_t nbytes, 
   for (int pass = 0; pass < 2; pass++) {
     d_tile_cnt = aa.take<uint32_t>(dec_tiles + 1);
     d_cnt_tmp = aa.take<uint32_t>(cdiv(dec_tiles, kScanTile) + 8);
-    d_cps = aa.take<uint32_t>(nbytes + 1);
+    d_cps = v->keep_debug ? aa.take<uint32_t>(nbytes + 1) : nullptr;  // raw code points: debug copy only
     d_cls = aa.take<uint8_t>(nbytes + 1);
     if (pass == 0) aa.commit();
   }
   WP_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(uint32_t) * 16, st));
   WP_HIP(hipMemsetAsync(c->d_used, 0, sizeof(uint32_t) * kCpTableSize, st));
   hipLaunchKernelGGL(decode_count_kernel, dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes, d_tile_cnt,
-                     reinterpret_cast<unsigned long long *>(c->d_scalars + 2));
+                     reinterpret_cast<unsigned long long *>(c->d_scalars + 2), c->d_used);
   device_exclusive_scan(d_tile_cnt, d_tile_cnt, dec_tiles, d_cnt_tmp, c->d_scalars + 0, st);
-  hipLaunchKernelGGL(decode_write_kernel, dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes, d_tile_cnt, d_cps,
-                     d_cls, c->d_used, c->d_soft, static_cast<int>(hv.soft.size()));
   hipLaunchKernelGGL(mark_used_kernel, dim3(cdiv(std::max<size_t>(hv.stream.size(), 1), kBlock)), dim3(kBlock), 0,
                      st, c->d_stream, hv.stream.size(), c->d_used);
   device_exclusive_scan(c->d_used, c->d_lut, kCpTableSize, c->d_scan_tmp, c->d_scalars + 1, st);
@@ -257,15 +256,16 @@ static void encode_on_device(wp_vocab *v, const uint8_t *d_text, size_t nbytes, 
   const int bits = std::max(1, bit_length(sigma));  // symbols are 1..sigma, 0 = past the end
   Arena ab(&c->b_buf);
   if (sigma <= 255) {
-    run_sa_and_beyond<uint8_t>(v, c, ab, n_text, n, d_cps, d_cls, bits, n_ids_out);
+    run_sa_and_beyond<uint8_t>(v, c, ab, d_text, nbytes, d_tile_cnt, n_text, n, d_cps, d_cls, bits, n_ids_out);
   } else {
-    run_sa_and_beyond<uint32_t>(v, c, ab, n_text, n, d_cps, d_cls, bits, n_ids_out);
+    run_sa_and_beyond<uint32_t>(v, c, ab, d_text, nbytes, d_tile_cnt, n_text, n, d_cps, d_cls, bits, n_ids_out);
   }
 }
 
 template <typename SymT>
-static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text, size_t n, const uint32_t *d_cps,
-                              const uint8_t *d_cls, int bits, size_t *n_ids_out) {
+static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t *d_text, size_t nbytes,
+                              const uint32_t *d_tile_prefix, size_t n_text, size_t n, uint32_t *d_cps, uint8_t *d_cls,
+                              int bits, size_t *n_ids_out) {
   hipStream_t st = c->stream;
   const HostVocab &hv = v->hv;
   wp_stats &S = v->stats;
@@ -356,15 +356,16 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
   }
 
   // ---------------- S build: dense symbols, symbol code, round-0 keys ----------------
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(map_symbols_kernel<SymT>), dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, d_cps,
-                     n_text, c->d_stream, n, c->d_lut, d_sym);
+  WP_HIP(hipMemsetAsync(c->d_symhist, 0, sizeof(uint32_t) * 256, st));
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(decode_write_kernel<SymT>), dim3(cdiv(nbytes, kDecTile)), dim3(kBlock), 0, st,
+                     d_text, nbytes, d_tile_prefix, c->d_lut, d_sym, d_cls, d_cps, c->d_soft,
+                     static_cast<int>(hv.soft.size()), c->d_symhist);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(map_vocab_symbols_kernel<SymT>), dim3(cdiv(n - n_text, kBlock)), dim3(kBlock), 0,
+                     st, c->d_stream, n_text, n, c->d_lut, d_sym, c->d_symhist);
   SymbolCode code;
   static const bool allow_variable = !(getenv("WP_FIXED_CODE") && atoi(getenv("WP_FIXED_CODE")) != 0);
   if (sizeof(SymT) == 1 && allow_variable) {
     // symbol frequencies -> optimal order-preserving code (host, <= 256 symbols) -> device tables
-    WP_HIP(hipMemsetAsync(c->d_symhist, 0, sizeof(uint32_t) * 256, st));
-    hipLaunchKernelGGL(sym_hist_kernel, dim3(cdiv(n, kBlock * 64)), dim3(kBlock), 0, st,
-                       reinterpret_cast<const uint8_t *>(d_sym), n, c->d_symhist);
     std::vector<uint32_t> h32(256);
     WP_HIP(hipMemcpyAsync(h32.data(), c->d_symhist, sizeof(uint32_t) * 256, hipMemcpyDeviceToHost, st));
     WP_HIP(hipStreamSynchronize(st));
@@ -513,7 +514,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, size_t n_text,
                          d_rf, d_rb);
     }
     if (M > 0) {
-      hipLaunchKernelGGL(mark_cover_kernel, dim3(1), dim3(kBlock), 0, st, d_minfo, d_rf, d_rb, M, d_cover_f,
+      hipLaunchKernelGGL(mark_cover_kernel, dim3(4), dim3(kBlock), 0, st, d_minfo, d_rf, d_rb, M, d_cover_f,
                          d_cover_b);
     }
     hipLaunchKernelGGL(piece_starts_kernel, dim3(cdiv(std::max(M, 1), kBlock)), dim3(kBlock), 0, st, mv, n, d_ps0);
@@ -832,7 +833,11 @@ int wp_linear_debug_fetch(const wp_vocab *v, int which, int32_t *out, size_t cap
         src = which == 4 ? d.best_scratch : d.best_scratch + d.n;
         break;
       }
-      case 6: src = d.cps; cnt = d.n_text; break;
+      case 6:
+        if (!d.cps) throw std::invalid_argument("code points are kept only with WP_OPT_KEEP_DEBUG");
+        src = d.cps;
+        cnt = d.n_text;
+        break;
       default: throw std::invalid_argument("unknown debug array");
     }
     if (cnt > capacity) throw std::invalid_argument("debug buffer too small");

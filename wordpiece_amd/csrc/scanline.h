@@ -252,39 +252,30 @@ struct MarkView {
   const int32_t *cover_f, *cover_b;
 };
 
-// single workgroup: running max / min per class over the (sorted) marks
+// grid = 4 workgroups (class x direction): running max / min per class over the (sorted) marks
 __global__ __launch_bounds__(kBlock) void mark_cover_kernel(const uint32_t *__restrict__ minfo,
                                                             const int32_t *__restrict__ reach_fwd,
                                                             const int32_t *__restrict__ reach_bwd, int M,
                                                             int32_t *__restrict__ cover_f, int32_t *__restrict__ cover_b) {
   __shared__ int32_t smx[8];
-  __shared__ int32_t carry[2];
-  const int tid = threadIdx.x;
-  for (int c = 0; c < 2; c++) {
-    if (tid == 0) carry[0] = -2147483647 - 1;
-    __syncthreads();
-    for (int base = 0; base < M; base += kBlock) {  // forward running max
-      const int q = base + tid;
-      int32_t v = -2147483647 - 1;
-      if (q < M && static_cast<int>(minfo[q] >> kMarkClsShift) == c) v = reach_fwd[q];
-      const int32_t inc = max(block_incl_max(v, smx), carry[0]);
-      if (q < M) cover_f[static_cast<size_t>(c) * M + q] = inc;
-      __syncthreads();
-      if (tid == kBlock - 1) carry[0] = inc;
-      __syncthreads();
+  __shared__ int32_t carry;
+  const int tid = threadIdx.x, c = blockIdx.x >> 1, back = blockIdx.x & 1;
+  constexpr int32_t kNone = -2147483647 - 1;
+  if (tid == 0) carry = kNone;
+  __syncthreads();
+  for (int base = 0; base < M; base += kBlock) {
+    // forward: running max of reach_fwd; backward: running min of reach_bwd as a max of negated values
+    const int q = back ? M - 1 - (base + tid) : base + tid;
+    int32_t v = kNone;
+    if (q >= 0 && q < M && static_cast<int>(minfo[q] >> kMarkClsShift) == c) v = back ? -reach_bwd[q] - 1 : reach_fwd[q];
+    const int32_t inc = max(block_incl_max(v, smx), carry);
+    if (q >= 0 && q < M) {
+      if (back) cover_b[static_cast<size_t>(c) * M + q] = inc == kNone ? 2147483647 : -(inc + 1);
+      else cover_f[static_cast<size_t>(c) * M + q] = inc;
     }
-    if (tid == 0) carry[1] = -2147483647 - 1;  // backward running min as a max of negated values
     __syncthreads();
-    for (int base = 0; base < M; base += kBlock) {
-      const int q = M - 1 - (base + tid);
-      int32_t v = -2147483647 - 1;
-      if (q >= 0 && static_cast<int>(minfo[q] >> kMarkClsShift) == c) v = -reach_bwd[q] - 1;
-      const int32_t inc = max(block_incl_max(v, smx), carry[1]);
-      if (q >= 0) cover_b[static_cast<size_t>(c) * M + q] = inc == (-2147483647 - 1) ? 2147483647 : -(inc + 1);
-      __syncthreads();
-      if (tid == kBlock - 1) carry[1] = inc;
-      __syncthreads();
-    }
+    if (tid == kBlock - 1) carry = inc;
+    __syncthreads();
   }
 }
 
