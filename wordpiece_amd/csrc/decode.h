@@ -176,19 +176,18 @@ __global__ __launch_bounds__(kBlock) void mark_used_kernel(const uint32_t *__res
 }
 
 // the separator and the vocab stream behind the text: sym[n_text + k] (dense, order-preserving
-// symbol id >= 1; 0 is reserved for "past the end"), plus their share of the symbol histogram
+// symbol id >= 1; 0 is reserved for "past the end").  (The vocab stream is left out of the symbol
+// histogram: it only steers the code lengths, and a few 1e5 same-address atomics are slow.)
 template <typename SymT>
 __global__ __launch_bounds__(kBlock) void map_vocab_symbols_kernel(const uint32_t *__restrict__ vocab_cps,
                                                                    size_t n_text, size_t n,
                                                                    const uint32_t *__restrict__ lut_excl,
-                                                                   SymT *__restrict__ sym,
-                                                                   uint32_t *__restrict__ sym_hist) {
+                                                                   SymT *__restrict__ sym) {
   size_t i = n_text + static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
   const uint32_t c = i == n_text ? 1u : vocab_cps[i - n_text - 1];
   const uint32_t sv = lut_excl[c] + 1u;
   sym[i] = static_cast<SymT>(sv);
-  if (sizeof(SymT) == 1) atomicAdd(&sym_hist[sv & 255u], 1u);
 }
 
 // Device copy of the symbol code (code.h).  uniform_bits > 0: fixed width, tables unused.

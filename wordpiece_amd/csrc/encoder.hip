@@ -361,7 +361,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                      d_text, nbytes, d_tile_prefix, c->d_lut, d_sym, d_cls, d_cps, c->d_soft,
                      static_cast<int>(hv.soft.size()), c->d_symhist);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(map_vocab_symbols_kernel<SymT>), dim3(cdiv(n - n_text, kBlock)), dim3(kBlock), 0,
-                     st, c->d_stream, n_text, n, c->d_lut, d_sym, c->d_symhist);
+                     st, c->d_stream, n_text, n, c->d_lut, d_sym);
   SymbolCode code;
   static const bool allow_variable = !(getenv("WP_FIXED_CODE") && atoi(getenv("WP_FIXED_CODE")) != 0);
   if (sizeof(SymT) == 1 && allow_variable) {

@@ -1,10 +1,17 @@
-// radix_sort.h — stable LSD radix sort of (key, uint32 value) pairs, 8-bit digits.
+// radix_sort.h — stable LSD radix sort of (key, uint32 value) pairs, 8-bit digits (WP_RADIX_BITS).
 //
-// One pass = histogram kernel + scan + scatter kernel.  A tile is 256 threads x ITEMS
-// keys.  Inside a tile each wave ranks its keys with a wave64 match-any (ballot per digit
-// bit) against per-wave digit counters staged in LDS, the tile is reordered through LDS and
-// written back so that every digit run is a coalesced segment.  HBM traffic per pass and
+// One pass = histogram kernel + column scan (spine, apply) + scatter kernel.  A tile is 256
+// threads x ITEMS keys.  Inside a tile each wave ranks its keys with a wave64 match-any (one ballot
+// per digit bit) against per-wave digit counters staged in LDS, the tile is reordered through LDS
+// and written back so that every digit run is a coalesced segment.  HBM traffic per pass and
 // element: sizeof(Key) (histogram) + 2*(sizeof(Key)+4) (scatter).
+//
+// A single-pass ("onesweep", chained look-back) variant was built and measured slower on MI355X
+// (0.93 ms vs 0.77 ms per 1e8-element pass): every look-back step is a cross-XCD miss and ~770
+// tiles are in flight, so the chain costs more than the separate 8-byte histogram read.  It was
+// removed again; see DESIGN.md.  9-bit digits (7 instead of 8 passes over the 63-bit keys) were
+// measured too: each pass gets 13 % slower (512 bins: shorter runs, twice the counter work), the
+// whole encode only 1 % faster, so 8 bits stay the default.
 #pragma once
 #include <cstdlib>
 #include <string>
@@ -14,8 +21,12 @@
 
 namespace wp {
 
-constexpr int kRadixBits = 8;
+#ifndef WP_RADIX_BITS
+#define WP_RADIX_BITS 8
+#endif
+constexpr int kRadixBits = WP_RADIX_BITS;
 constexpr int kRadixBins = 1 << kRadixBits;
+constexpr int kBinsPerThread = kRadixBins / kBlock;
 
 template <typename KeyT>
 struct RadixCfg {
@@ -26,7 +37,7 @@ struct RadixCfg {
   static constexpr int kTile = kBlock * kItems;
 };
 
-__device__ __forceinline__ uint64_t wave_match_any8(uint32_t digit) {
+__device__ __forceinline__ uint64_t wave_match_any_digit(uint32_t digit) {
   uint64_t peers = ~0ull;
 #pragma unroll
   for (int b = 0; b < kRadixBits; b++) {
@@ -37,9 +48,9 @@ __device__ __forceinline__ uint64_t wave_match_any8(uint32_t digit) {
   return peers;
 }
 
-// Offset table, tile-major: table[tile * 256 + digit].  The histogram kernel fills it with the
-// per-tile digit counts (one coalesced 1 KiB row per workgroup) and adds the row into the sums of
-// its chunk of kColChunk tiles; a single-workgroup spine turns the chunk sums into exclusive
+// Offset table, tile-major: table[tile * kRadixBins + digit].  The histogram kernel fills it with
+// the per-tile digit counts (one coalesced row per workgroup) and adds the row into the sums
+// of its chunk of kColChunk tiles; a single-workgroup spine turns the chunk sums into exclusive
 // prefixes in (digit, tile) order; the apply kernel rewrites every row as global offsets.
 constexpr int kColChunk = 64;
 
@@ -50,7 +61,8 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
                                                             uint32_t *__restrict__ chunk_sums) {
   constexpr int ITEMS = RadixCfg<KeyT>::kItems;
   __shared__ uint32_t sh[kRadixBins];
-  sh[threadIdx.x] = 0;
+#pragma unroll
+  for (int q = 0; q < kBinsPerThread; q++) sh[q * kBlock + threadIdx.x] = 0;
   __syncthreads();
   const size_t base = static_cast<size_t>(blockIdx.x) * RadixCfg<KeyT>::kTile;
 #pragma unroll
@@ -62,19 +74,25 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
     }
   }
   __syncthreads();
-  const uint32_t c = sh[threadIdx.x];
-  table[static_cast<size_t>(blockIdx.x) * kRadixBins + threadIdx.x] = c;
-  if (c) atomicAdd(&chunk_sums[static_cast<size_t>(blockIdx.x / kColChunk) * kRadixBins + threadIdx.x], c);
+#pragma unroll
+  for (int q = 0; q < kBinsPerThread; q++) {
+    const int d = q * kBlock + threadIdx.x;
+    const uint32_t c = sh[d];
+    table[static_cast<size_t>(blockIdx.x) * kRadixBins + d] = c;
+    if (c) atomicAdd(&chunk_sums[static_cast<size_t>(blockIdx.x / kColChunk) * kRadixBins + d], c);
+  }
 }
 
-// single workgroup of 1024 threads = 4 chunk ranges x 256 digits:
+// single workgroup of 1024 threads = kSpineParts chunk ranges x kRadixBins digits:
 // chunk_pre[chunk][d] = exclusive prefix of chunk_sums in (digit, chunk) order
-constexpr int kSpineParts = 4;
-__global__ __launch_bounds__(kSpineParts * kRadixBins) void radix_spine_kernel(
-    const uint32_t *__restrict__ chunk_sums, uint32_t *__restrict__ chunk_pre, unsigned nchunks) {
+constexpr int kSpineThreads = 1024;
+constexpr int kSpineParts = kSpineThreads / kRadixBins;
+__global__ __launch_bounds__(kSpineThreads) void radix_spine_kernel(const uint32_t *__restrict__ chunk_sums,
+                                                                    uint32_t *__restrict__ chunk_pre,
+                                                                    unsigned nchunks) {
   __shared__ uint32_t part[kSpineParts][kRadixBins];
-  __shared__ uint32_t wtot[4];
-  const int d = threadIdx.x & (kRadixBins - 1), q = threadIdx.x >> 8;
+  __shared__ uint32_t wtot[kRadixBins / kWave];
+  const int d = threadIdx.x & (kRadixBins - 1), q = threadIdx.x / kRadixBins;
   const unsigned per = (nchunks + kSpineParts - 1) / kSpineParts;
   const unsigned c0 = min(nchunks, q * per), c1 = min(nchunks, c0 + per);
   uint32_t sum = 0;
@@ -88,15 +106,13 @@ __global__ __launch_bounds__(kSpineParts * kRadixBins) void radix_spine_kernel(
     if (i < q) before += v;
     total += v;
   }
-  // exclusive scan of total[d] over the 256 digits (threads 0..255 = waves 0..3 hold q == 0)
+  // exclusive scan of total[d] over the digits (threads 0..kRadixBins-1 hold q == 0)
   uint32_t inc = wave_incl_sum(q == 0 ? total : 0u);
   if (q == 0 && (threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
   __syncthreads();
-  const int wd = d >> 6;  // wave that owns digit d in the q == 0 row
-  uint32_t base_d = 0;
   if (q == 0) {
-    for (int i = 0; i < wd; i++) base_d += wtot[i];
-    base_d += inc - total;
+    uint32_t base_d = inc - total;
+    for (int i = 0; i < (d >> 6); i++) base_d += wtot[i];
     part[0][d] = base_d;  // every thread has finished reading part[][] (barrier above)
   }
   __syncthreads();
@@ -108,12 +124,12 @@ __global__ __launch_bounds__(kSpineParts * kRadixBins) void radix_spine_kernel(
   }
 }
 
-__global__ __launch_bounds__(kBlock) void radix_apply_kernel(uint32_t *__restrict__ table,
-                                                             const uint32_t *__restrict__ chunk_sums,
-                                                             unsigned ntiles) {
+__global__ __launch_bounds__(kRadixBins) void radix_apply_kernel(uint32_t *__restrict__ table,
+                                                                 const uint32_t *__restrict__ chunk_pre,
+                                                                 unsigned ntiles) {
   const int d = threadIdx.x;
   const unsigned t0 = blockIdx.x * kColChunk, t1 = min(ntiles, t0 + kColChunk);
-  uint32_t run = chunk_sums[static_cast<size_t>(blockIdx.x) * kRadixBins + d];
+  uint32_t run = chunk_pre[static_cast<size_t>(blockIdx.x) * kRadixBins + d];
   for (unsigned t = t0; t < t1; t++) {
     const size_t i = static_cast<size_t>(t) * kRadixBins + d;
     const uint32_t v = table[i];
@@ -126,7 +142,7 @@ template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
     uint32_t *__restrict__ vout, size_t n, int begin_bit, uint32_t mask,
-    const uint32_t *__restrict__ goff, unsigned ntiles) {
+    const uint32_t *__restrict__ goff) {
   constexpr int ITEMS = RadixCfg<KeyT>::kItems;
   constexpr int TILE = RadixCfg<KeyT>::kTile;
   constexpr int WAVES = kBlock / kWave;
@@ -143,7 +159,10 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
   const uint32_t tile_count = static_cast<uint32_t>(min(static_cast<size_t>(TILE), n - tile_base));
 
 #pragma unroll
-  for (int i = 0; i < WAVES; i++) wcnt[i][tid] = 0;
+  for (int i = 0; i < WAVES; i++) {
+#pragma unroll
+    for (int q = 0; q < kBinsPerThread; q++) wcnt[i][q * kBlock + tid] = 0;
+  }
   __syncthreads();
 
   KeyT key[ITEMS];
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     // out-of-range slots (only at the very end of the last tile) take the top bin: they are the
     // last keys in tile order, hence rank after every valid key and are never written back
     const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : (kRadixBins - 1);
-    const uint64_t peers = wave_match_any8(d);
+    const uint64_t peers = wave_match_any_digit(d);
     const int leader = __ffsll(static_cast<long long>(peers)) - 1;
     uint32_t old = 0;
     if (lane == leader) {
@@ -175,18 +194,30 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     rnk[r] = old + __popcll(peers & lt);
   }
   __syncthreads();
-  // per digit (thread = digit): exclusive scan across waves, then across digits
-  uint32_t tot = 0;
+  // thread t owns bins [t*kBinsPerThread, +kBinsPerThread): exclusive scan across waves, then bins
+  uint32_t tot = 0, binbase[kBinsPerThread];
 #pragma unroll
-  for (int i = 0; i < WAVES; i++) {
-    uint32_t c = wcnt[i][tid];
-    wcnt[i][tid] = tot;
-    tot += c;
+  for (int q = 0; q < kBinsPerThread; q++) {
+    const int bin = tid * kBinsPerThread + q;
+    uint32_t t = 0;
+#pragma unroll
+    for (int i = 0; i < WAVES; i++) {
+      uint32_t c = wcnt[i][bin];
+      wcnt[i][bin] = t;
+      t += c;
+    }
+    binbase[q] = tot;
+    tot += t;
   }
   uint32_t all;
-  uint32_t ds = block_excl_sum(tot, ssum, all);
-  dstart[tid] = ds;
-  gbase[tid] = goff[static_cast<size_t>(blockIdx.x) * kRadixBins + tid] - ds;
+  const uint32_t ex = block_excl_sum(tot, ssum, all);
+#pragma unroll
+  for (int q = 0; q < kBinsPerThread; q++) {
+    const int bin = tid * kBinsPerThread + q;
+    const uint32_t ds = ex + binbase[q];
+    dstart[bin] = ds;
+    gbase[bin] = goff[static_cast<size_t>(blockIdx.x) * kRadixBins + bin] - ds;
+  }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
@@ -253,181 +284,16 @@ struct RadixStats {
   EventSpans spans;  // around every scatter launch
 };
 
-// ---- single-pass ("onesweep") variant: chained scan with decoupled look-back -------------------
-// One upfront kernel histograms every digit position of the whole sort in a single read of the
-// keys.  Each pass is then ONE kernel: a workgroup takes the next tile number from an atomic
-// ticket (so every lower-numbered tile is already running or done), ranks its tile exactly as
-// above, publishes its 256 digit counts as {flag, count} words and looks back over the
-// predecessors' words until it meets an inclusive prefix.  Words are single 32-bit agent-scope
-// atomics (flag and value travel together, no fence needed); rows are tile-major (1 KiB per tile),
-// so every look-back step is one coalesced wave load.
-constexpr uint32_t kOsFlagLocal = 1u << 30;   // value = this tile's count
-constexpr uint32_t kOsFlagIncl = 2u << 30;    // value = inclusive prefix over tiles 0..t
-constexpr uint32_t kOsValueMask = (1u << 30) - 1u;
-constexpr int kOsMaxPasses = 8;
-
-struct OsPasses {
-  int n;
-  int begin[kOsMaxPasses];
-  uint32_t mask[kOsMaxPasses];
-};
-
-constexpr int kOsHistItems = 16;
-template <typename KeyT>
-__global__ __launch_bounds__(kBlock) void radix_global_hist_kernel(const KeyT *__restrict__ keys, size_t n,
-                                                                   OsPasses ps, uint32_t *__restrict__ ghist) {
-  __shared__ uint32_t sh[kOsMaxPasses][kRadixBins];
-  for (int p = 0; p < ps.n; p++) sh[p][threadIdx.x] = 0;
-  __syncthreads();
-  const size_t base = static_cast<size_t>(blockIdx.x) * (kBlock * kOsHistItems);
-#pragma unroll 4
-  for (int j = 0; j < kOsHistItems; j++) {
-    const size_t i = base + static_cast<size_t>(j) * kBlock + threadIdx.x;
-    if (i < n) {
-      const KeyT k = keys[i];
-      for (int p = 0; p < ps.n; p++) atomicAdd(&sh[p][static_cast<uint32_t>(k >> ps.begin[p]) & ps.mask[p]], 1u);
-    }
-  }
-  __syncthreads();
-  for (int p = 0; p < ps.n; p++) {
-    const uint32_t c = sh[p][threadIdx.x];
-    if (c) atomicAdd(&ghist[p * kRadixBins + threadIdx.x], c);
-  }
-}
-
-// exclusive scan of each pass's 256 bins (one workgroup per pass)
-__global__ __launch_bounds__(kBlock) void radix_digit_base_kernel(uint32_t *__restrict__ ghist) {
-  __shared__ uint32_t sm[8];
-  uint32_t *h = ghist + blockIdx.x * kRadixBins;
-  uint32_t tot;
-  const uint32_t ex = block_excl_sum(h[threadIdx.x], sm, tot);
-  h[threadIdx.x] = ex;
-}
-
-template <typename KeyT>
-__global__ __launch_bounds__(kBlock) void radix_onesweep_kernel(
-    const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
-    uint32_t *__restrict__ vout, size_t n, int begin_bit, uint32_t mask, const uint32_t *__restrict__ digit_base,
-    uint32_t *__restrict__ status, uint32_t *__restrict__ ticket) {
-  constexpr int ITEMS = RadixCfg<KeyT>::kItems;
-  constexpr int TILE = RadixCfg<KeyT>::kTile;
-  constexpr int WAVES = kBlock / kWave;
-  __shared__ uint32_t wcnt[WAVES][kRadixBins];
-  __shared__ uint32_t dstart[kRadixBins];
-  __shared__ uint32_t gbase[kRadixBins];
-  __shared__ uint32_t ssum[8];
-  __shared__ uint32_t s_tile;
-  __shared__ KeyT skeys[TILE];
-  __shared__ uint32_t svals[TILE];
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-#pragma unroll
-  for (int i = 0; i < WAVES; i++) wcnt[i][tid] = 0;
-  __syncthreads();
-  const uint32_t tile = s_tile;
-  const size_t tile_base = static_cast<size_t>(tile) * TILE;
-  const size_t wave_base = tile_base + static_cast<size_t>(w) * (kWave * ITEMS);
-  const uint32_t tile_count = static_cast<uint32_t>(min(static_cast<size_t>(TILE), n - tile_base));
-
-  KeyT key[ITEMS];
-  uint32_t val[ITEMS];
-  uint32_t rnk[ITEMS];
-#pragma unroll
-  for (int r = 0; r < ITEMS; r++) {
-    size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
-    const bool valid = i < n;
-    key[r] = valid ? kin[i] : static_cast<KeyT>(~static_cast<KeyT>(0));
-    val[r] = valid ? vin[i] : 0u;
-  }
-  volatile uint32_t *mycnt = wcnt[w];
-  const uint64_t lt = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int r = 0; r < ITEMS; r++) {
-    size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
-    const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : (kRadixBins - 1);
-    const uint64_t peers = wave_match_any8(d);
-    const int leader = __ffsll(static_cast<long long>(peers)) - 1;
-    uint32_t old = 0;
-    if (lane == leader) {
-      old = mycnt[d];
-      mycnt[d] = old + __popcll(peers);
-    }
-    old = __shfl(old, leader, kWave);
-    rnk[r] = old + __popcll(peers & lt);
-  }
-  __syncthreads();
-  uint32_t tot = 0;
-#pragma unroll
-  for (int i = 0; i < WAVES; i++) {
-    uint32_t c = wcnt[i][tid];
-    wcnt[i][tid] = tot;
-    tot += c;
-  }
-  // the padding slots of the last tile were counted in the top bin: take them out again
-  if (tid == kRadixBins - 1) tot -= (TILE - tile_count);
-  // publish the tile's count for digit `tid`, then look back
-  uint32_t *row = status + static_cast<size_t>(tile) * kRadixBins;
-  __hip_atomic_store(&row[tid], kOsFlagLocal | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint32_t excl = 0;
-  for (long long t = static_cast<long long>(tile) - 1; t >= 0;) {
-    const uint32_t v = __hip_atomic_load(status + static_cast<size_t>(t) * kRadixBins + tid, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t flag = v & ~kOsValueMask;
-    if (flag == 0) {
-      __builtin_amdgcn_s_sleep(1);
-      continue;
-    }
-    excl += v & kOsValueMask;
-    if (flag == kOsFlagIncl) break;
-    t--;
-  }
-  __hip_atomic_store(&row[tid], kOsFlagIncl | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint32_t all;
-  const uint32_t tot_padded = tid == kRadixBins - 1 ? tot + (TILE - tile_count) : tot;
-  uint32_t ds = block_excl_sum(tot_padded, ssum, all);
-  dstart[tid] = ds;
-  gbase[tid] = digit_base[tid] + excl - ds;
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < ITEMS; r++) {
-    size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
-    const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : (kRadixBins - 1);
-    const uint32_t pos = dstart[d] + wcnt[w][d] + rnk[r];
-    skeys[pos] = key[r];
-    svals[pos] = val[r];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < ITEMS; j++) {
-    const uint32_t k = static_cast<uint32_t>(j) * kBlock + tid;
-    if (k < tile_count) {
-      const KeyT kk = skeys[k];
-      const uint32_t d = static_cast<uint32_t>(kk >> begin_bit) & mask;
-      const size_t o = static_cast<size_t>(gbase[d]) + k;
-      kout[o] = kk;
-      vout[o] = svals[k];
-    }
-  }
-}
-
 template <typename KeyT>
 size_t radix_tmp_words(size_t n) {
   size_t ntiles = cdiv(n, RadixCfg<KeyT>::kTile);
   size_t h = ntiles * kRadixBins;
-  return h + 2 * (cdiv(ntiles, kColChunk) + 1) * kRadixBins + kOsMaxPasses * kRadixBins + 64;
+  return h + 2 * (cdiv(ntiles, kColChunk) + 1) * kRadixBins + 64;
 }
 
 struct BitRange {
   int begin, end;
 };
-
-inline bool radix_use_onesweep() {
-  // measured on MI355X: the chained look-back costs more than the separate histogram pass (every
-  // look-back step is a cross-XCD miss), so the two-kernel pass is the default
-  static const bool v = getenv("WP_RADIX") && std::string(getenv("WP_RADIX")) == "onesweep";
-  return v;
-}
 
 // Sorts the given bit ranges of the keys, least significant range first (stable LSD).  Data
 // ping-pongs between (k0,v0) and (k1,v1); returns 0 or 1 = which pair holds the result.
@@ -438,56 +304,31 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
   int cur = 0;
   if (n == 0) return cur;
   const unsigned ntiles = cdiv(n, RadixCfg<KeyT>::kTile);
+  const unsigned nchunks = cdiv(ntiles, kColChunk);
   const size_t h = static_cast<size_t>(ntiles) * kRadixBins;
-  OsPasses ps;
-  ps.n = 0;
+  uint32_t *table = tmp, *chunk_sums = tmp + h;
+  uint32_t *chunk_pre = chunk_sums + static_cast<size_t>(nchunks + 1) * kRadixBins;
   for (int r = 0; r < nranges; r++) {
     for (int b = ranges[r].begin; b < ranges[r].end; b += kRadixBits) {
-      if (ps.n >= kOsMaxPasses) throw std::length_error("too many radix passes");
-      ps.begin[ps.n] = b;
-      ps.mask[ps.n] = (1u << min(kRadixBits, ranges[r].end - b)) - 1u;
-      ps.n++;
-    }
-  }
-  if (ps.n == 0) return cur;
-  const bool onesweep = radix_use_onesweep();
-  const unsigned nchunks = cdiv(ntiles, kColChunk);
-  uint32_t *status = tmp, *chunk_sums = tmp + h;                // classic: offset table + chunk sums
-  uint32_t *chunk_pre = chunk_sums + static_cast<size_t>(nchunks + 1) * kRadixBins;
-  uint32_t *ghist = chunk_pre + static_cast<size_t>(nchunks + 1) * kRadixBins;  // onesweep: digit bases
-  uint32_t *tickets = ghist + kOsMaxPasses * kRadixBins;        // onesweep: one ticket per pass
-  if (onesweep) {
-    WP_HIP(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (kOsMaxPasses * kRadixBins + kOsMaxPasses), st));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_global_hist_kernel<KeyT>), dim3(cdiv(n, kBlock * kOsHistItems)),
-                       dim3(kBlock), 0, st, k0, n, ps, ghist);
-    hipLaunchKernelGGL(radix_digit_base_kernel, dim3(ps.n), dim3(kBlock), 0, st, ghist);
-  }
-  for (int p = 0; p < ps.n; p++) {
-    KeyT *ki = cur ? k1 : k0, *ko = cur ? k0 : k1;
-    uint32_t *vi = cur ? v1 : v0, *vo = cur ? v0 : v1;
-    if (onesweep) {
-      WP_HIP(hipMemsetAsync(status, 0, sizeof(uint32_t) * h, st));
-      if (stats) stats->spans.begin(st);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_onesweep_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, vi, ko,
-                         vo, n, ps.begin[p], ps.mask[p], ghist + p * kRadixBins, status, tickets + p);
-    } else {
+      const uint32_t mask = (1u << min(kRadixBits, ranges[r].end - b)) - 1u;
+      KeyT *ki = cur ? k1 : k0, *ko = cur ? k0 : k1;
+      uint32_t *vi = cur ? v1 : v0, *vo = cur ? v0 : v1;
       WP_HIP(hipMemsetAsync(chunk_sums, 0, sizeof(uint32_t) * static_cast<size_t>(nchunks) * kRadixBins, st));
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, n,
-                         ps.begin[p], ps.mask[p], status, chunk_sums);
-      hipLaunchKernelGGL(radix_spine_kernel, dim3(1), dim3(kSpineParts * kRadixBins), 0, st, chunk_sums, chunk_pre,
-                         nchunks);
-      hipLaunchKernelGGL(radix_apply_kernel, dim3(nchunks), dim3(kBlock), 0, st, status, chunk_pre, ntiles);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, n, b, mask,
+                         table, chunk_sums);
+      hipLaunchKernelGGL(radix_spine_kernel, dim3(1), dim3(kSpineThreads), 0, st, chunk_sums, chunk_pre, nchunks);
+      hipLaunchKernelGGL(radix_apply_kernel, dim3(nchunks), dim3(kRadixBins), 0, st, table, chunk_pre, ntiles);
       if (stats) stats->spans.begin(st);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, vi, ko,
-                         vo, n, ps.begin[p], ps.mask[p], status, ntiles);
+                         vo, n, b, mask, table);
+      WP_LAUNCH_CHECK();
+      if (stats) {
+        stats->spans.end(st);
+        stats->passes++;
+        stats->elems += static_cast<long long>(n);
+      }
+      cur ^= 1;
     }
-    WP_LAUNCH_CHECK();
-    if (stats) {
-      stats->spans.end(st);
-      stats->passes++;
-      stats->elems += static_cast<long long>(n);
-    }
-    cur ^= 1;
   }
   return cur;
 }
