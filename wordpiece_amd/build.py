@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwordpiece_amd.so")
 RUNNER = os.path.join(HERE, "runner")
+CPPTEST = os.path.join(HERE, "test_word_piece")
 SOURCES = ["encoder.hip", "word_piece.cpp"]
 ARCH = "gfx950"
 
@@ -41,6 +42,13 @@ def build(force=False, verbose=False):
     if force or _newer(RUNNER, deps + [LIB]):
         cmd = [hipcc, "-O2", "-std=c++17", "-o", RUNNER, os.path.join(CSRC, "runner.cpp"),
                "-L" + HERE, "-lwordpiece_amd", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    test_src = os.path.join(os.path.dirname(HERE), "tests", "cpp", "test_word_piece.cpp")
+    if os.path.exists(test_src) and (force or _newer(CPPTEST, deps + [LIB, test_src])):
+        cmd = [hipcc, "-O2", "-std=c++17", "-o", CPPTEST, test_src, "-L" + HERE, "-lwordpiece_amd",
+               "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
