@@ -172,6 +172,7 @@ def test_english_16mb_ids_and_properties():
     finally:
         O.use_libsais(False)
     gv = W.Vocab(vocab)
+    gv.set_option(W.WP_OPT_KEEP_DEBUG, 1)  # keeps the suffix array for debug_fetch(1)
     ids = gv.encode(text)
     assert np.array_equal(ids, exp)
     st = gv.stats()

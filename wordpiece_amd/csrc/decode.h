@@ -194,18 +194,29 @@ __global__ __launch_bounds__(kBlock) void map_vocab_symbols_kernel(const uint32_
 struct DevCode {
   const uint16_t *cw;
   const uint8_t *len;
-  const uint8_t *first_len;  // [4096]
+  const uint8_t *first_len;  // [4096] then multi[4096] right behind it
   int uniform_bits;
 };
+constexpr int kDecodeTableBytes = 2 * 4096;
 
-// number of complete codewords inside the first t bits of a 63-bit key (t <= 63)
-__device__ __forceinline__ int count_key_symbols(uint64_t key, int t, const uint8_t *first_len, int uniform_bits) {
+// number of complete codewords inside the first t bits of a 63-bit key (t <= 63).  tab = first_len
+// [4096] followed by multi[4096]: whole 12-bit windows first, single codewords for the rest.
+__device__ __forceinline__ int count_key_symbols(uint64_t key, int t, const uint8_t *tab, int uniform_bits) {
   if (uniform_bits) return t / uniform_bits;
   int pos = 0, cnt = 0;
   while (true) {
     const int sh = 63 - pos - 12;
     const uint32_t w = static_cast<uint32_t>(sh >= 0 ? (key >> sh) : (key << -sh)) & 0xfffu;
-    const int l = first_len[w];
+    const uint32_t m = tab[4096 + w];
+    const int nb = m & 15;
+    if (nb == 0 || pos + nb > t) break;
+    pos += nb;
+    cnt += m >> 4;
+  }
+  while (true) {
+    const int sh = 63 - pos - 12;
+    const uint32_t w = static_cast<uint32_t>(sh >= 0 ? (key >> sh) : (key << -sh)) & 0xfffu;
+    const int l = tab[w];
     if (pos + l > t) break;
     pos += l;
     cnt++;
@@ -224,18 +235,14 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
                                                              uint64_t *__restrict__ keys,
                                                              uint32_t *__restrict__ vals) {
   __shared__ uint32_t ss[kKeyTile + kKeyHalo];
-  __shared__ uint16_t scw[256];
-  __shared__ uint8_t slen[256];
+  __shared__ uint32_t stab[256];  // (len << 16) | codeword
   const size_t base = static_cast<size_t>(blockIdx.x) * kKeyTile;
   for (int k = threadIdx.x; k < kKeyTile + kKeyHalo; k += kBlock) {
     size_t i = base + k;
     ss[k] = i < n ? static_cast<uint32_t>(sym[i]) : 0u;
   }
   const int ub = code.uniform_bits;
-  if (!ub) {
-    scw[threadIdx.x] = code.cw[threadIdx.x];
-    slen[threadIdx.x] = code.len[threadIdx.x];
-  }
+  if (!ub) stab[threadIdx.x] = (static_cast<uint32_t>(code.len[threadIdx.x]) << 16) | code.cw[threadIdx.x];
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < kKeyItems; j++) {
@@ -246,8 +253,9 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
       int used = 0, q = li;
       while (used < 63) {
         const uint32_t sv = ss[q++];
-        const int l = ub ? ub : slen[sv];
-        const uint32_t c = ub ? sv : scw[sv];
+        const uint32_t e = ub ? 0u : stab[sv];
+        const int l = ub ? ub : static_cast<int>(e >> 16);
+        const uint32_t c = ub ? sv : (e & 0xffffu);
         const int take = min(l, 63 - used);
         key = (key << take) | (c >> (l - take));
         used += take;

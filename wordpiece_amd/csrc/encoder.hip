@@ -177,7 +177,7 @@ static Context *get_context(wp_vocab *v) {
   WP_HIP(hipMalloc(&c->d_lut, sizeof(uint32_t) * kCpTableSize));
   WP_HIP(hipMalloc(&c->d_scan_tmp, sizeof(uint32_t) * (cdiv(kCpTableSize, kScanTile) + 8)));
   WP_HIP(hipMalloc(&c->d_scalars, sizeof(uint32_t) * 16));
-  WP_HIP(hipMalloc(&c->d_code, 512 + 256 + 4096));
+  WP_HIP(hipMalloc(&c->d_code, 512 + 256 + kDecodeTableBytes));
   WP_HIP(hipMalloc(&c->d_symhist, sizeof(uint32_t) * 256));
   WP_HIP(hipHostMalloc(&c->h_scalars, sizeof(uint32_t) * 16));
   for (auto &e : c->ev) WP_HIP(hipEventCreate(&e));
@@ -311,7 +311,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     AS0 = ar.take<uint32_t>(n);
     AS1 = ar.take<uint32_t>(n);
     AG = ar.take<uint32_t>(n);
-    d_sa = ar.take<uint32_t>(n);
+    d_sa = (v->keep_debug || v->lcp_kasai) ? ar.take<uint32_t>(n) : nullptr;
     d_rank = ar.take<RankEntry>(n);
     AD0 = ar.take<uint32_t>(n);
     AD1 = ar.take<uint32_t>(n);
@@ -378,10 +378,11 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   }
   DevCode dcode{reinterpret_cast<const uint16_t *>(c->d_code), c->d_code + 512, c->d_code + 768, code.uniform_bits};
   if (!code.uniform_bits) {
-    std::vector<uint8_t> blob(512 + 256 + 4096, 0);
+    std::vector<uint8_t> blob(512 + 256 + kDecodeTableBytes, 0);
     std::memcpy(blob.data(), code.cw.data(), code.cw.size() * sizeof(uint16_t));
     std::memcpy(blob.data() + 512, code.len.data(), code.len.size());
     std::memcpy(blob.data() + 768, code.first_len.data(), 4096);
+    std::memcpy(blob.data() + 768 + 4096, code.multi.data(), 4096);
     WP_HIP(hipMemcpyAsync(c->d_code, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
     WP_HIP(hipStreamSynchronize(st));  // blob is a stack object
   }
@@ -395,17 +396,20 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   const DepthRule rule{need_depth, full ? 1 : 0};
   // after every rerank: classify the new groups (large ones take the global path next round)
   auto classify_groups = [&](size_t list_len) {
+    if (list_len <= static_cast<size_t>(kLsMaxGroup)) return false;  // no group can be large
     const size_t cap = list_len / 2 + 1;  // a group has >= 2 entries
     hipLaunchKernelGGL(group_classify_kernel, dim3(cdiv(cap, kBlock)), dim3(kBlock), 0, st, d_ghead,
                        c->d_scalars + 5, d_large_id, d_large_off, cap);
     device_exclusive_scan(d_large_id, d_large_id, cap, d_gscan_tmp, c->d_scalars + 6, st, c->d_scalars + 5);
     device_exclusive_scan(d_large_off, d_large_off, cap, d_gscan_tmp, c->d_scalars + 7, st, c->d_scalars + 5);
+    return true;
   };
   int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, kKeyBits, d_radix_tmp, st, &c->rstats);
   uint64_t *keys = cur ? K1 : K0;
   uint32_t *vals = cur ? V1 : V0, *other_vals = cur ? V0 : V1;
   uint32_t *slots = AS0, *other_slots = AS1;
   uint32_t *adep = AD0, *other_dep = AD1;
+  bool classified = false;
   {
     const unsigned tiles = cdiv(n, kRrTile);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<true>), dim3(tiles), dim3(kBlock), 0, st, keys, vals, n,
@@ -421,11 +425,11 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                        AG, adep, d_ghead, d_gdepth);
     hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, vals, hd, n, d_rank);
     WP_LAUNCH_CHECK();
-    classify_groups(n);
+    classified = classify_groups(n);
   }
   fetch_scalars(c, 8);
   size_t n_act = c->h_scalars[4], n_groups = c->h_scalars[5];
-  size_t n_large_groups = c->h_scalars[6], n_large = c->h_scalars[7];
+  size_t n_large_groups = classified ? c->h_scalars[6] : 0, n_large = classified ? c->h_scalars[7] : 0;
   int rounds = 1;
   S.active_per_round[0] = static_cast<int64_t>(n);
   uint32_t *avals = other_vals;  // active list values live in the vals buffer the sort did not end in
@@ -460,12 +464,12 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, svals, hd, n_act,
                        d_rank);
     WP_LAUNCH_CHECK();
-    classify_groups(n_act);
+    classified = classify_groups(n_act);
     fetch_scalars(c, 8);
     n_act = c->h_scalars[4];
     n_groups = c->h_scalars[5];
-    n_large_groups = c->h_scalars[6];
-    n_large = c->h_scalars[7];
+    n_large_groups = classified ? c->h_scalars[6] : 0;
+    n_large = classified ? c->h_scalars[7] : 0;
     std::swap(slots, other_slots);
     std::swap(adep, other_dep);
     avals = nvals;
@@ -821,7 +825,10 @@ int wp_linear_debug_fetch(const wp_vocab *v, int which, int32_t *out, size_t cap
     size_t cnt = d.n;
     switch (which) {
       case 0: src = d.sym; break;
-      case 1: src = d.sa; break;
+      case 1:
+        if (!d.sa) throw std::invalid_argument("the suffix array is kept only with WP_OPT_KEEP_DEBUG");
+        src = d.sa;
+        break;
       case 2: src = d.rank; break;
       case 3: src = d.lcp; cnt = d.n - 1; break;
       case 4:

@@ -65,9 +65,11 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
                                                             DepthRule rule, uint32_t *__restrict__ tdep,
                                                             RerankAgg *__restrict__ agg) {
   __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
-  __shared__ uint8_t s_fl[1 << 12];
+  __shared__ uint8_t s_fl[kDecodeTableBytes];
   if (ROUND0 && !uniform_bits) {
-    for (int q = threadIdx.x; q < (1 << 12); q += kBlock) s_fl[q] = first_len[q];
+    for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
+      reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
+    }
     __syncthreads();
   }
   const int lane = lane_id(), w = wave_id();
@@ -207,9 +209,11 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep, uint32_t *__restrict__ ghead,
     uint32_t *__restrict__ gdepth) {
   __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
-  __shared__ uint8_t s_fl[1 << 12];
+  __shared__ uint8_t s_fl[kDecodeTableBytes];
   if (ROUND0 && !uniform_bits) {
-    for (int q = threadIdx.x; q < (1 << 12); q += kBlock) s_fl[q] = first_len[q];
+    for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
+      reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
+    }
   }
   const int lane = lane_id(), w = wave_id();
   const size_t wave_base = static_cast<size_t>(blockIdx.x) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
       const uint32_t head_slot = ROUND0 ? static_cast<uint32_t>(head) : slots[head];
       const uint64_t me = keys[k];
       const bool single = f && (k + 1 == m || keys[k + 1] != me);
-      sa[x] = v;
+      if (sa) sa[x] = v;  // the suffix array itself is only kept for debug fetches / the Kasai kernel
       // new rank entry of suffix v, scattered to the rank table afterwards.  In rounds >= 1 the
       // first subgroup of an old group keeps its rank (its head is the old head): left unchanged.
       bool changed = true;
