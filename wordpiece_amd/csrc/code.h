@@ -16,7 +16,10 @@
 
 namespace wp {
 
-constexpr int kKeyBits = 63;
+#ifndef WP_KEY_BITS
+#define WP_KEY_BITS 63
+#endif
+constexpr int kKeyBits = WP_KEY_BITS;  // bits of the codeword stream kept in a round-0 key (<= 63)
 constexpr int kMaxCodeLen = 12;  // decode table: 2^12 entries (first codeword length of a 12-bit window)
 
 struct SymbolCode {

@@ -6,6 +6,7 @@
 // is always a decode point (a valid sequence only ever swallows continuation bytes), so every
 // byte is classified independently and valid leads are stream-compacted.
 #pragma once
+#include "code.h"
 #include "primitives.h"
 
 namespace wp {
@@ -199,13 +200,13 @@ struct DevCode {
 };
 constexpr int kDecodeTableBytes = 2 * 4096;
 
-// number of complete codewords inside the first t bits of a 63-bit key (t <= 63).  tab = first_len
+// number of complete codewords inside the first t bits of a kKeyBits-bit key (t <= kKeyBits).  tab = first_len
 // [4096] followed by multi[4096]: whole 12-bit windows first, single codewords for the rest.
 __device__ __forceinline__ int count_key_symbols(uint64_t key, int t, const uint8_t *tab, int uniform_bits) {
   if (uniform_bits) return t / uniform_bits;
   int pos = 0, cnt = 0;
   while (true) {
-    const int sh = 63 - pos - 12;
+    const int sh = kKeyBits - pos - 12;
     const uint32_t w = static_cast<uint32_t>(sh >= 0 ? (key >> sh) : (key << -sh)) & 0xfffu;
     const uint32_t m = tab[4096 + w];
     const int nb = m & 15;
@@ -214,7 +215,7 @@ __device__ __forceinline__ int count_key_symbols(uint64_t key, int t, const uint
     cnt += m >> 4;
   }
   while (true) {
-    const int sh = 63 - pos - 12;
+    const int sh = kKeyBits - pos - 12;
     const uint32_t w = static_cast<uint32_t>(sh >= 0 ? (key >> sh) : (key << -sh)) & 0xfffu;
     const int l = tab[w];
     if (pos + l > t) break;
@@ -251,12 +252,12 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
     if (i < n) {
       uint64_t key = 0;
       int used = 0, q = li;
-      while (used < 63) {
+      while (used < kKeyBits) {
         const uint32_t sv = ss[q++];
         const uint32_t e = ub ? 0u : stab[sv];
         const int l = ub ? ub : static_cast<int>(e >> 16);
         const uint32_t c = ub ? sv : (e & 0xffffu);
-        const int take = min(l, 63 - used);
+        const int take = min(l, kKeyBits - used);
         key = (key << take) | (c >> (l - take));
         used += take;
       }

@@ -80,6 +80,8 @@ static int bit_length(uint64_t v) {
 struct Context {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // side stream: latency-bound helpers overlap the bandwidth-bound kernels
+  hipEvent_t evs[2] = {};         // fork / join
   // vocab tables on the device
   uint32_t *d_stream = nullptr, *d_elig_start = nullptr, *d_elig_info = nullptr, *d_soft = nullptr;
   int32_t *d_elig_id = nullptr, *d_tok_len = nullptr;
@@ -138,6 +140,10 @@ static void destroy_context(Context *c) {
   for (auto &e : c->ev) {
     if (e) (void)hipEventDestroy(e);
   }
+  for (auto &e : c->evs) {
+    if (e) (void)hipEventDestroy(e);
+  }
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -166,6 +172,8 @@ static Context *get_context(wp_vocab *v) {
   }
   WP_HIP(hipSetDevice(c->device));
   WP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  WP_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  for (auto &e : c->evs) WP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const HostVocab &hv = v->hv;
   c->d_stream = upload(hv.stream, c->stream);
   c->d_elig_start = upload(hv.elig_start, c->stream);
@@ -267,6 +275,16 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                               const uint32_t *d_tile_prefix, size_t n_text, size_t n, uint32_t *d_cps, uint8_t *d_cls,
                               int bits, size_t *n_ids_out) {
   hipStream_t st = c->stream;
+  hipStream_t st2 = c->stream2;
+  // st2 starts after everything queued on st so far / st continues after everything queued on st2
+  auto fork = [&] {
+    WP_HIP(hipEventRecord(c->evs[0], st));
+    WP_HIP(hipStreamWaitEvent(st2, c->evs[0], 0));
+  };
+  auto join = [&] {
+    WP_HIP(hipEventRecord(c->evs[1], st2));
+    WP_HIP(hipStreamWaitEvent(st, c->evs[1], 0));
+  };
   const HostVocab &hv = v->hv;
   wp_stats &S = v->stats;
   const bool full = v->full_depth || hv.n_dup_eligible > 0 || v->lcp_kasai;
@@ -287,7 +305,9 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   SymT *d_sym = nullptr;
   uint64_t *K0 = nullptr, *K1 = nullptr;
   RankEntry *d_rank = nullptr;
-  uint32_t *AD0 = nullptr, *AD1 = nullptr, *d_tdep = nullptr, *d_gdepth = nullptr;
+  uint32_t *AD0 = nullptr, *AD1 = nullptr, *d_tdep = nullptr, *d_gdepth = nullptr, *d_anchors = nullptr,
+           *d_anchor_cnt = nullptr, *d_anchor_tmp = nullptr;
+  int32_t *d_emit = nullptr;
   uint32_t *V0 = nullptr, *V1 = nullptr, *AS0 = nullptr, *AS1 = nullptr, *AG = nullptr, *d_sa = nullptr,
            *d_radix_tmp = nullptr, *d_mslot0 = nullptr, *d_mslot1 = nullptr, *d_midx0 = nullptr,
            *d_midx1 = nullptr, *d_minfo = nullptr, *d_tile_mlo = nullptr, *d_emit_cnt = nullptr,
@@ -350,6 +370,10 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     d_pval_p = ar.take<int32_t>(P + 1);
     d_pval_s = ar.take<int32_t>(P + 1);
     d_bidx = ar.take<uint32_t>(static_cast<size_t>(nbuckets) + 2);
+    d_emit = ar.take<int32_t>(n_text + 1);
+    d_anchors = ar.take<uint32_t>(n_text + 1);
+    d_anchor_cnt = ar.take<uint32_t>(emit_tiles + 1);
+    d_anchor_tmp = ar.take<uint32_t>(cdiv(emit_tiles, kScanTile) + 8);
     d_emit_cnt = ar.take<uint32_t>(emit_tiles + 1);
     d_emit_tmp = ar.take<uint32_t>(cdiv(emit_tiles, kScanTile) + 8);
     if (pass == 0) ar.commit();
@@ -395,13 +419,14 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   // ---------------- suffix array by prefix doubling ----------------
   const DepthRule rule{need_depth, full ? 1 : 0};
   // after every rerank: classify the new groups (large ones take the global path next round)
+  // (runs on the side stream, next to the rank scatter)
   auto classify_groups = [&](size_t list_len) {
     if (list_len <= static_cast<size_t>(kLsMaxGroup)) return false;  // no group can be large
     const size_t cap = list_len / 2 + 1;  // a group has >= 2 entries
-    hipLaunchKernelGGL(group_classify_kernel, dim3(cdiv(cap, kBlock)), dim3(kBlock), 0, st, d_ghead,
+    hipLaunchKernelGGL(group_classify_kernel, dim3(cdiv(cap, kBlock)), dim3(kBlock), 0, st2, d_ghead,
                        c->d_scalars + 5, d_large_id, d_large_off, cap);
-    device_exclusive_scan(d_large_id, d_large_id, cap, d_gscan_tmp, c->d_scalars + 6, st, c->d_scalars + 5);
-    device_exclusive_scan(d_large_off, d_large_off, cap, d_gscan_tmp, c->d_scalars + 7, st, c->d_scalars + 5);
+    device_exclusive_scan(d_large_id, d_large_id, cap, d_gscan_tmp, c->d_scalars + 6, st2, c->d_scalars + 5);
+    device_exclusive_scan(d_large_off, d_large_off, cap, d_gscan_tmp, c->d_scalars + 7, st2, c->d_scalars + 5);
     return true;
   };
   int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, kKeyBits, d_radix_tmp, st, &c->rstats);
@@ -410,22 +435,35 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   uint32_t *slots = AS0, *other_slots = AS1;
   uint32_t *adep = AD0, *other_dep = AD1;
   bool classified = false;
+  if (n_text > 0) {
+    // side stream: the anchor list and the cleared emit array only need the class bytes; they run
+    // next to the (gather/scatter bound) rerank kernels rather than next to the streaming radix passes
+    fork();
+    const unsigned atiles = cdiv(n_text, kScanTile);
+    WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st2));
+    hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls, n_text, d_anchor_cnt);
+    device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st2);
+    hipLaunchKernelGGL(anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls, n_text, d_anchor_cnt,
+                       d_anchors);
+  }
   {
     const unsigned tiles = cdiv(n, kRrTile);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<true>), dim3(tiles), dim3(kBlock), 0, st, keys, vals, n,
                        static_cast<const uint32_t *>(nullptr), static_cast<const RankEntry *>(nullptr),
                        static_cast<const uint32_t *>(nullptr), n, dcode.first_len, dcode.uniform_bits, rule, d_tdep,
                        d_agg);
-    hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kBlock), 0, st, d_agg, static_cast<size_t>(tiles),
+    hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kRrSpineThreads), 0, st, d_agg, static_cast<size_t>(tiles),
                        c->d_scalars + 4, d_ghead);
     RankEntry *hd = reinterpret_cast<RankEntry *>(cur ? K0 : K1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
                        vals, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), d_tdep, n,
                        d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp, slots, other_vals,
                        AG, adep, d_ghead, d_gdepth);
+    fork();
     hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, vals, hd, n, d_rank);
     WP_LAUNCH_CHECK();
     classified = classify_groups(n);
+    join();
   }
   fetch_scalars(c, 8);
   size_t n_act = c->h_scalars[4], n_groups = c->h_scalars[5];
@@ -440,31 +478,36 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     // small groups: one LDS-resident segmented sort per window of the list
     uint64_t *skeys = K0, *kfree = K1;
     uint32_t *svals = spare_vals, *nvals = avals;  // avals is free again once the sorts have consumed it
+    if (n_large > 0) fork();
     hipLaunchKernelGGL(local_sort_kernel, dim3(cdiv(n_act, kLsT)), dim3(kBlock), 0, st, avals, AG, adep, n_act,
                        d_ghead, static_cast<uint32_t>(n_groups), d_rank, n, rb, skeys, svals);
-    if (n_large > 0) {  // large groups: extract, global radix sort on (dense large id, second key), write back
-      hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, avals, AG, adep, n_act,
-                         d_ghead, d_large_id, d_large_off, d_rank, n, K1, LV0, LPOS);
+    if (n_large > 0) {  // large groups (side stream, disjoint list positions): extract, global radix sort on
+                        // (dense large id, second key), write back
+      hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st2, avals, AG, adep,
+                         n_act, d_ghead, d_large_id, d_large_off, d_rank, n, K1, LV0, LPOS);
       const int lgb = bit_length(n_large_groups > 0 ? n_large_groups - 1 : 0);
       const BitRange ranges[2] = {{0, rb}, {32, 32 + lgb}};
-      const int lc = radix_sort_ranges<uint64_t>(K1, LV0, LK1, LV1, n_large, ranges, lgb > 0 ? 2 : 1, d_radix_tmp, st,
+      const int lc = radix_sort_ranges<uint64_t>(K1, LV0, LK1, LV1, n_large, ranges, lgb > 0 ? 2 : 1, d_radix_tmp, st2,
                                                  &c->rstats);
-      hipLaunchKernelGGL(large_writeback_kernel, dim3(cdiv(n_large, kBlock)), dim3(kBlock), 0, st, lc ? LK1 : K1,
+      hipLaunchKernelGGL(large_writeback_kernel, dim3(cdiv(n_large, kBlock)), dim3(kBlock), 0, st2, lc ? LK1 : K1,
                          lc ? LV1 : LV0, LPOS, n_large, AG, skeys, svals);
+      join();
     }
     const unsigned tiles = cdiv(n_act, kRrTile);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<false>), dim3(tiles), dim3(kBlock), 0, st, skeys, svals,
                        n_act, adep, d_rank, d_gdepth, n, dcode.first_len, dcode.uniform_bits, rule, d_tdep, d_agg);
-    hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kBlock), 0, st, d_agg, static_cast<size_t>(tiles),
+    hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kRrSpineThreads), 0, st, d_agg, static_cast<size_t>(tiles),
                        c->d_scalars + 4, d_ghead);
     RankEntry *hd = reinterpret_cast<RankEntry *>(kfree);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
                        svals, slots, adep, d_tdep, n_act, d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule,
                        d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead, d_gdepth);
+    fork();
     hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, svals, hd, n_act,
                        d_rank);
     WP_LAUNCH_CHECK();
     classified = classify_groups(n_act);
+    join();
     fetch_scalars(c, 8);
     n_act = c->h_scalars[4];
     n_groups = c->h_scalars[5];
@@ -535,21 +578,13 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[5], st));
 
   // ---------------- greedy walk + id stream ----------------
-  int32_t *d_emit = reinterpret_cast<int32_t *>(V0);
   int32_t *d_ids = reinterpret_cast<int32_t *>(V1);
   size_t n_ids = 0;
   if (n_text > 0) {
-    WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st));
     static const int walk_dbg = getenv("WP_WALK_DBG") ? atoi(getenv("WP_WALK_DBG")) : 0;
     WalkArgs wa{d_cls, n_text, d_rank, steps, c->d_tok_len, hv.unk_id, d_emit, walk_dbg};
-    // anchors -> list (count, scan, write), then one lane per anchor.  The anchor count stays on the
-    // device; the walk grid is sized for the worst case (every position an anchor) only when small,
-    // otherwise for one anchor per two positions, which text cannot exceed... so use n_text.
-    const unsigned atiles = cdiv(n_text, kScanTile);
-    uint32_t *d_anchors = reinterpret_cast<uint32_t *>(K1);  // K1 is free after the suffix sort (8n bytes)
-    hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, n_text, d_emit_cnt);
-    device_exclusive_scan(d_emit_cnt, d_emit_cnt, atiles, d_emit_tmp, c->d_scalars + 10, st);
-    hipLaunchKernelGGL(anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, n_text, d_emit_cnt, d_anchors);
+    // the anchor list and the cleared emit array were produced on the side stream; the anchor count
+    // stays on the device, so the grid covers the worst case (every position an anchor)
     hipLaunchKernelGGL(walk_kernel, dim3(cdiv(n_text, kBlock)), dim3(kBlock), 0, st, wa, d_anchors,
                        c->d_scalars + 10, n_text);
     const unsigned tiles = cdiv(n_text, kScanTile);

@@ -119,9 +119,12 @@ __global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const uint32_t *__r
 }
 
 // single block: in-place exclusive scan of m values; writes the grand total to *total
+// (n_dev, optional: only the tiles that hold elements below *n_dev are non-zero and visited)
 __global__ __launch_bounds__(kBlock) void scan_spine_kernel(uint32_t *__restrict__ sums, size_t m,
-                                                            uint32_t *__restrict__ total) {
+                                                            uint32_t *__restrict__ total,
+                                                            const uint32_t *__restrict__ n_dev) {
   __shared__ uint32_t sm[8];
+  if (n_dev) m = min(m, (static_cast<size_t>(*n_dev) + kScanTile - 1) / kScanTile);
   uint32_t carry = 0;
   for (size_t base = 0; base < m; base += kBlock) {
     size_t i = base + threadIdx.x;
@@ -169,7 +172,7 @@ inline void device_exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, u
   }
   unsigned tiles = cdiv(n, kScanTile);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(tiles), dim3(kBlock), 0, st, in, n, tmp, n_dev);
-  hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(kBlock), 0, st, tmp, static_cast<size_t>(tiles), total);
+  hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(kBlock), 0, st, tmp, static_cast<size_t>(tiles), total, n_dev);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(tiles), dim3(kBlock), 0, st, in, out, n, tmp, n_dev);
   WP_LAUNCH_CHECK();
 }

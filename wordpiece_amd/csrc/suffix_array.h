@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
       if (!sg) {
         uint32_t nd;
         if (ROUND0) {
-          nd = static_cast<uint32_t>(count_key_symbols(keys[k], 63, s_fl, uniform_bits));
+          nd = static_cast<uint32_t>(count_key_symbols(keys[k], kKeyBits, s_fl, uniform_bits));
         } else {
           const uint32_t d = adep[k];
           const size_t t = static_cast<size_t>(vals[k]) + d;
@@ -115,40 +115,61 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
   }
 }
 
-// single block: exclusive prefix over tiles (running max of last_flag, sums of the counts);
-// totals[0] = n_active, totals[1] = n_heads
-__global__ __launch_bounds__(kBlock) void rerank_spine_kernel(RerankAgg *__restrict__ agg, size_t tiles,
-                                                              uint32_t *__restrict__ totals,
-                                                              uint32_t *__restrict__ ghead) {
-  __shared__ uint32_t sm[8];
-  __shared__ int32_t smx[8];
-  __shared__ int32_t shifted[kBlock];
-  uint32_t ca = 0, ch = 0;
-  int32_t cm = 0;
-  for (size_t base = 0; base < tiles; base += kBlock) {
-    size_t i = base + threadIdx.x;
+// single workgroup of 1024 threads: exclusive prefix over tiles (running max of last_flag, sums of
+// the counts); totals[0] = n_active, totals[1] = n_heads
+constexpr int kRrSpineThreads = 1024;
+__global__ __launch_bounds__(kRrSpineThreads) void rerank_spine_kernel(RerankAgg *__restrict__ agg, size_t tiles,
+                                                                       uint32_t *__restrict__ totals,
+                                                                       uint32_t *__restrict__ ghead) {
+  constexpr int WAVES = kRrSpineThreads / kWave;
+  __shared__ uint32_t wa[WAVES], wh[WAVES], wm[WAVES];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t ca = 0, ch = 0, cm = 0;  // carries: active, heads, running max of last_flag
+  for (size_t base = 0; base < tiles; base += kRrSpineThreads) {
+    const size_t i = base + threadIdx.x;
     RerankAgg a = {0, 0, 0};
     if (i < tiles) a = agg[i];
-    uint32_t ta, th;
-    uint32_t ea = block_excl_sum(a.n_active, sm, ta);
-    uint32_t eh = block_excl_sum(a.n_heads, sm, th);
-    // exclusive running max: shift by one thread
-    int32_t inc = block_incl_max(static_cast<int32_t>(a.last_flag), smx);
+    // inclusive scans inside the wave
+    uint32_t ia = a.n_active, ih = a.n_heads, im = a.last_flag;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const uint32_t ta = __shfl_up(ia, d, kWave), th = __shfl_up(ih, d, kWave), tm = __shfl_up(im, d, kWave);
+      if (lane >= d) {
+        ia += ta;
+        ih += th;
+        im = max(im, tm);
+      }
+    }
+    if (lane == kWave - 1) {
+      wa[w] = ia;
+      wh[w] = ih;
+      wm[w] = im;
+    }
     __syncthreads();
-    shifted[threadIdx.x] = inc;
-    __syncthreads();
-    int32_t exm = threadIdx.x == 0 ? 0 : shifted[threadIdx.x - 1];
-    int32_t blockmax = shifted[kBlock - 1];
+    uint32_t ba = ca, bh = ch, bm = cm, ta = 0, th = 0, tm = 0;
+#pragma unroll
+    for (int q = 0; q < WAVES; q++) {
+      if (q < w) {
+        ba += wa[q];
+        bh += wh[q];
+        bm = max(bm, wm[q]);
+      }
+      ta += wa[q];
+      th += wh[q];
+      tm = max(tm, wm[q]);
+    }
+    // exclusive values for this tile
+    const uint32_t pm = __shfl_up(im, 1, kWave);
     if (i < tiles) {
       RerankAgg o;
-      o.last_flag = static_cast<uint32_t>(max(cm, exm));
-      o.n_active = ca + ea;
-      o.n_heads = ch + eh;
+      o.n_active = ba + ia - a.n_active;
+      o.n_heads = bh + ih - a.n_heads;
+      o.last_flag = lane == 0 ? bm : max(bm, pm);
       agg[i] = o;
     }
     ca += ta;
     ch += th;
-    cm = max(cm, blockmax);
+    cm = max(cm, tm);
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
           int32_t l = -1;
           if (f) {
             const uint64_t d = me ^ keys[k - 1];
-            l = count_key_symbols(me, __clzll(static_cast<long long>(d)) - 1, s_fl, uniform_bits);
+            l = count_key_symbols(me, __clzll(static_cast<long long>(d)) - (64 - kKeyBits), s_fl, uniform_bits);
           }
           lcp[x - 1] = l;
         }
