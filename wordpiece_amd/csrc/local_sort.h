@@ -12,6 +12,7 @@
 // entries.
 #pragma once
 #include "primitives.h"
+#include "radix_sort.h"
 #include "suffix_array.h"
 
 namespace wp {
@@ -23,16 +24,6 @@ constexpr int kLsItems = kLsCap / kBlock;   // 16
 constexpr int kLsBits = 10;
 constexpr int kLsBins = 1 << kLsBits;
 constexpr int kLsGroupBits = 12;  // local group number < kLsCap
-
-__device__ __forceinline__ uint64_t wave_match_any_bits(uint32_t digit, int nbits) {
-  uint64_t peers = ~0ull;
-  for (int b = 0; b < nbits; b++) {
-    const bool bit = (digit >> b) & 1u;
-    const uint64_t m = __ballot(bit);
-    peers &= bit ? m : ~m;
-  }
-  return peers;
-}
 
 // group g is [ghead[g], ghead[g+1]); large[g] = size > kLsMaxGroup; the exclusive scans of
 // large[] (dense number of the large group) and of the large sizes (offset in the large list)
@@ -140,7 +131,6 @@ __global__ __launch_bounds__(kBlock) void local_sort_kernel(const uint32_t *__re
     }
   }
   const int total_bits = rbits + kLsGroupBits;
-  const uint64_t lt = (1ull << lane) - 1ull;
   for (int shift = 0; shift < total_bits; shift += kLsBits) {
     for (int q = tid; q < WAVES * kLsBins; q += kBlock) (&wc[0][0])[q] = 0;
     __syncthreads();
@@ -151,15 +141,7 @@ __global__ __launch_bounds__(kBlock) void local_sort_kernel(const uint32_t *__re
       rnk[r] = 0;
       if (r < nr) {  // wave-uniform
         const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & (kLsBins - 1);
-        const uint64_t peers = wave_match_any_bits(d, kLsBits);
-        const int leader = __ffsll(static_cast<long long>(peers)) - 1;
-        uint32_t old = 0;
-        if (lane == leader) {
-          old = mycnt[d];
-          mycnt[d] = old + __popcll(peers);
-        }
-        old = __shfl(old, leader, kWave);
-        rnk[r] = old + __popcll(peers & lt);
+        rnk[r] = wave_rank_digit<kLsBits>(mycnt, d, lane);
       }
     }
     __syncthreads();

@@ -37,15 +37,35 @@ struct RadixCfg {
   static constexpr int kTile = kBlock * kItems;
 };
 
-__device__ __forceinline__ uint64_t wave_match_any_digit(uint32_t digit) {
-  uint64_t peers = ~0ull;
+// Lanes of the wave holding the same digit, as (mismatch_lo, mismatch_hi) complemented.  Per digit
+// bit: one ballot, and "my bit differs from lane l's bit" = ballot ^ sign-extended(my bit), OR-ed
+// into a per-lane mismatch mask (6 vector ops per bit).
+template <int BITS>
+__device__ __forceinline__ void wave_match_any(uint32_t digit, uint32_t &peers_lo, uint32_t &peers_hi) {
+  uint32_t mlo = 0, mhi = 0;
 #pragma unroll
-  for (int b = 0; b < kRadixBits; b++) {
-    const bool bit = (digit >> b) & 1u;
-    const uint64_t m = __ballot(bit);
-    peers &= bit ? m : ~m;
+  for (int b = 0; b < BITS; b++) {
+    const int32_t ext = static_cast<int32_t>(digit << (31 - b)) >> 31;  // -1 if bit b is set, else 0
+    const uint64_t m = __ballot(ext != 0);
+    mlo |= static_cast<uint32_t>(m) ^ static_cast<uint32_t>(ext);
+    mhi |= static_cast<uint32_t>(m >> 32) ^ static_cast<uint32_t>(ext);
   }
-  return peers;
+  peers_lo = ~mlo;
+  peers_hi = ~mhi;
+}
+
+// Stable rank of this lane's key among the keys of its wave round: `cnt` is the wave's LDS counter
+// row.  Every peer reads the counter, the lowest peer lane adds the peer count (the row is private
+// to the wave and LDS operations of a wave execute in order).
+template <int BITS>
+__device__ __forceinline__ uint32_t wave_rank_digit(volatile uint32_t *cnt, uint32_t digit, int lane) {
+  uint32_t plo, phi;
+  wave_match_any<BITS>(digit, plo, phi);
+  const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));  // peers in lower lanes
+  const uint32_t total = __popc(plo) + __popc(phi);
+  const uint32_t old = cnt[digit];
+  if (below == 0) cnt[digit] = old + total;  // the lowest peer lane
+  return old + below;
 }
 
 // Offset table, tile-major: table[tile * kRadixBins + digit].  The histogram kernel fills it with
@@ -138,6 +158,15 @@ __global__ __launch_bounds__(kRadixBins) void radix_apply_kernel(uint32_t *__res
   }
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Mapping workgroup b to
+// tile (b % 8) * (ntiles / 8) + b / 8 gives every XCD a contiguous range of tiles: consecutive tiles
+// append to the same digit runs, so the partial 128-byte lines at the run ends meet in one L2 and
+// leave it as full lines.  Placement only affects speed, never the result.
+__device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned ntiles) {
+  const unsigned q = ntiles / 8, r = ntiles % 8, x = b % 8;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+}
+
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
@@ -154,7 +183,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
   __shared__ uint32_t svals[TILE];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const size_t tile_base = static_cast<size_t>(blockIdx.x) * TILE;
+  const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+  const size_t tile_base = static_cast<size_t>(tile) * TILE;
   const size_t wave_base = tile_base + static_cast<size_t>(w) * (kWave * ITEMS);
   const uint32_t tile_count = static_cast<uint32_t>(min(static_cast<size_t>(TILE), n - tile_base));
 
@@ -176,22 +206,13 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     val[r] = valid ? vin[i] : 0u;
   }
   volatile uint32_t *mycnt = wcnt[w];
-  const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
     // out-of-range slots (only at the very end of the last tile) take the top bin: they are the
     // last keys in tile order, hence rank after every valid key and are never written back
     const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : (kRadixBins - 1);
-    const uint64_t peers = wave_match_any_digit(d);
-    const int leader = __ffsll(static_cast<long long>(peers)) - 1;
-    uint32_t old = 0;
-    if (lane == leader) {
-      old = mycnt[d];
-      mycnt[d] = old + __popcll(peers);
-    }
-    old = __shfl(old, leader, kWave);
-    rnk[r] = old + __popcll(peers & lt);
+    rnk[r] = wave_rank_digit<kRadixBits>(mycnt, d, lane);
   }
   __syncthreads();
   // thread t owns bins [t*kBinsPerThread, +kBinsPerThread): exclusive scan across waves, then bins
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const int bin = tid * kBinsPerThread + q;
     const uint32_t ds = ex + binbase[q];
     dstart[bin] = ds;
-    gbase[bin] = goff[static_cast<size_t>(blockIdx.x) * kRadixBins + bin] - ds;
+    gbase[bin] = goff[static_cast<size_t>(tile) * kRadixBins + bin] - ds;
   }
   __syncthreads();
 #pragma unroll
