@@ -299,7 +299,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   const unsigned nbuckets = static_cast<unsigned>(((n - 1) >> bucket_shift) + 1);
 
   const size_t rr_tiles = cdiv(n, kRrTile);
-  const size_t radix_words = std::max(radix_tmp_words<uint64_t>(n), radix_tmp_words<uint32_t>(kStepsPerMark * std::max(M, 1) + 1));
+  const size_t radix_words = std::max(radix_tmp_words<uint64_t>(n), radix_tmp_words<uint32_t>(std::max<size_t>(n, kStepsPerMark * std::max(M, 1) + 1)));
   const size_t emit_tiles = cdiv(std::max<size_t>(n_text, 1), kScanTile);
 
   SymT *d_sym = nullptr;
@@ -429,6 +429,22 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     device_exclusive_scan(d_large_off, d_large_off, cap, d_gscan_tmp, c->d_scalars + 7, st2, c->d_scalars + 5);
     return true;
   };
+  // rank[dst[k]] = val[k].  Random 4-byte stores leave the L2s as partial lines; one radix pass over
+  // the top 8 bits of the destination first, and an XCD-aware scatter after it, lets the stores of a
+  // workgroup (and of its neighbours on the same XCD) fall into one ~1/256 window of the rank table
+  // and merge in that XCD's L2 (measured: 2.1 ms -> 1.0 ms for 1e8 stores).  t_dst/t_val: scratch.
+  static const int bin_bits = getenv("WP_BIN_BITS") ? atoi(getenv("WP_BIN_BITS")) : 8;
+  auto store_ranks = [&](uint32_t *dst, uint32_t *val, uint32_t *t_dst, uint32_t *t_val, size_t m) {
+    if (bin_bits > 0 && m >= (1u << 22)) {
+      const int hb = bit_length(n - 1);
+      const int bc = radix_sort_pairs<uint32_t>(dst, val, t_dst, t_val, m, std::max(0, hb - bin_bits), hb, d_radix_tmp,
+                                                st, nullptr);
+      hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kBlock)), dim3(kBlock), 0, st, bc ? t_dst : dst,
+                         bc ? t_val : val, m, d_rank, 1);
+    } else {
+      hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kBlock)), dim3(kBlock), 0, st, dst, val, m, d_rank, 0);
+    }
+  };
   int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, kKeyBits, d_radix_tmp, st, &c->rstats);
   uint64_t *keys = cur ? K1 : K0;
   uint32_t *vals = cur ? V1 : V0, *other_vals = cur ? V0 : V1;
@@ -460,7 +476,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                        d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp, slots, other_vals,
                        AG, adep, d_ghead, d_gdepth);
     fork();
-    hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, st, vals, hd, n, d_rank);
+    store_ranks(vals, hd, reinterpret_cast<uint32_t *>(hd) + n, reinterpret_cast<uint32_t *>(keys), n);
     WP_LAUNCH_CHECK();
     classified = classify_groups(n);
     join();
@@ -503,8 +519,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                        svals, slots, adep, d_tdep, n_act, d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule,
                        d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead, d_gdepth);
     fork();
-    hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, svals, hd, n_act,
-                       d_rank);
+    store_ranks(svals, hd, reinterpret_cast<uint32_t *>(hd) + n, reinterpret_cast<uint32_t *>(skeys), n_act);
     WP_LAUNCH_CHECK();
     classified = classify_groups(n_act);
     join();

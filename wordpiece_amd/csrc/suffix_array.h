@@ -207,10 +207,18 @@ __device__ __forceinline__ int32_t lcp_compare(const SymT *__restrict__ sym, siz
   return t;
 }
 
+// xcd != 0: workgroups of one XCD take a contiguous range of the list (used after the list has
+// been partitioned by destination, so that the stores of one XCD fall into one region and meet in
+// its L2)
 __global__ __launch_bounds__(kBlock) void scatter_pairs_kernel(const uint32_t *__restrict__ dst,
                                                                const RankEntry *__restrict__ val, size_t m,
-                                                               RankEntry *__restrict__ out) {
-  size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+                                                               RankEntry *__restrict__ out, int xcd) {
+  unsigned b = blockIdx.x;
+  if (xcd) {
+    const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8;
+    b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
+  }
+  size_t k = static_cast<size_t>(b) * kBlock + threadIdx.x;
   if (k < m) {
     const RankEntry v = val[k];
     if (v != kRankUnchanged) out[dst[k]] = v;
