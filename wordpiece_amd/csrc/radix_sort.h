@@ -80,24 +80,44 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
                                                             uint32_t *__restrict__ table,
                                                             uint32_t *__restrict__ chunk_sums) {
   constexpr int ITEMS = RadixCfg<KeyT>::kItems;
-  __shared__ uint32_t sh[kRadixBins];
+  constexpr int WAVES = kBlock / kWave;
+  // per-wave counters, bumped once per distinct digit of a wave round by its lowest lane (match-any):
+  // no LDS atomics, no same-address serialisation on skewed digits
+  __shared__ uint32_t sh[WAVES][kRadixBins];
 #pragma unroll
-  for (int q = 0; q < kBinsPerThread; q++) sh[q * kBlock + threadIdx.x] = 0;
+  for (int i = 0; i < WAVES; i++) {
+#pragma unroll
+    for (int q = 0; q < kBinsPerThread; q++) sh[i][q * kBlock + threadIdx.x] = 0;
+  }
   __syncthreads();
-  const size_t base = static_cast<size_t>(blockIdx.x) * RadixCfg<KeyT>::kTile;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  volatile uint32_t *mycnt = sh[w];
+  const size_t base = static_cast<size_t>(blockIdx.x) * RadixCfg<KeyT>::kTile + static_cast<size_t>(w) * (kWave * ITEMS);
+  KeyT key[ITEMS];
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
-    size_t i = base + static_cast<size_t>(j) * kBlock + threadIdx.x;
-    if (i < n) {
-      uint32_t d = static_cast<uint32_t>(keys[i] >> begin_bit) & mask;
-      atomicAdd(&sh[d], 1u);
-    }
+    const size_t i = base + static_cast<size_t>(j) * kWave + lane;
+    key[j] = i < n ? keys[i] : static_cast<KeyT>(0);
+  }
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    const size_t i = base + static_cast<size_t>(j) * kWave + lane;
+    const uint32_t d = static_cast<uint32_t>(key[j] >> begin_bit) & mask;
+    uint32_t plo, phi;
+    wave_match_any<kRadixBits>(d, plo, phi);
+    const uint64_t valid = __ballot(i < n);  // lanes past the end (last tile only) are not counted
+    plo &= static_cast<uint32_t>(valid);
+    phi &= static_cast<uint32_t>(valid >> 32);
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+    if (below == 0 && i < n) mycnt[d] = mycnt[d] + __popc(plo) + __popc(phi);
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < kBinsPerThread; q++) {
     const int d = q * kBlock + threadIdx.x;
-    const uint32_t c = sh[d];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < WAVES; i++) c += sh[i][d];
     table[static_cast<size_t>(blockIdx.x) * kRadixBins + d] = c;
     if (c) atomicAdd(&chunk_sums[static_cast<size_t>(blockIdx.x / kColChunk) * kRadixBins + d], c);
   }

@@ -125,10 +125,13 @@ __global__ __launch_bounds__(kRrSpineThreads) void rerank_spine_kernel(RerankAgg
   __shared__ uint32_t wa[WAVES], wh[WAVES], wm[WAVES];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint32_t ca = 0, ch = 0, cm = 0;  // carries: active, heads, running max of last_flag
+  RerankAgg nxt = {0, 0, 0};
+  if (threadIdx.x < tiles) nxt = agg[threadIdx.x];
   for (size_t base = 0; base < tiles; base += kRrSpineThreads) {
     const size_t i = base + threadIdx.x;
-    RerankAgg a = {0, 0, 0};
-    if (i < tiles) a = agg[i];
+    const RerankAgg a = nxt;  // loaded one iteration ahead: its latency hides behind the barriers
+    nxt = RerankAgg{0, 0, 0};
+    if (i + kRrSpineThreads < tiles) nxt = agg[i + kRrSpineThreads];
     // inclusive scans inside the wave
     uint32_t ia = a.n_active, ih = a.n_heads, im = a.last_flag;
 #pragma unroll
