@@ -85,12 +85,20 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # WP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks
+    # share devices, collectives go through host memory); the driver's runs use nccl (= RCCL).
+    backend = os.environ.get("WP_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective tensors live
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- workload: one shard per rank ----
     nbytes_target = int(args.mb * 1e6)
@@ -110,7 +118,7 @@ def main():
                     "%d-line BERT-like vocab" % (args.mb, len(vocab)))
     nbytes = len(text)
 
-    vocab_h = W.Vocab(vocab, device=local_rank)
+    vocab_h = W.Vocab(vocab, device=dev_index)
     vocab_h.set_option(W.WP_OPT_STAGE_TIMING, 1)
     pad = (-nbytes) % 16 + 16
     d_text = torch.zeros(nbytes + pad, dtype=torch.uint8, device=dev)
@@ -123,16 +131,16 @@ def main():
         d_ids, n_ids = vocab_h.encode_device(d_text.data_ptr(), nbytes)
         if world > 1:
             # the only collective: token ids -> rank 0 (counts first, then max-padded gather)
-            cnt = torch.tensor([n_ids], dtype=torch.int64, device=dev)
-            counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            cnt = torch.tensor([n_ids], dtype=torch.int64, device=cdev)
+            counts = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
             dist.all_gather(counts, cnt)
             mx = int(torch.stack(counts).max().item())
-            send = torch.zeros(mx, dtype=torch.int32, device=dev)
+            send = torch.zeros(mx, dtype=torch.int32, device=cdev)
             if n_ids:
-                send[:n_ids] = torch.as_tensor(_DevView(d_ids, n_ids), device=dev)
+                send[:n_ids] = torch.as_tensor(_DevView(d_ids, n_ids), device=dev).to(cdev)
             nonlocal gather_buf
             if rank == 0:
-                gather_buf = [torch.empty(mx, dtype=torch.int32, device=dev) for _ in range(world)]
+                gather_buf = [torch.empty(mx, dtype=torch.int32, device=cdev) for _ in range(world)]
             dist.gather(send, gather_buf if rank == 0 else None, dst=0)
         return n_ids
 
@@ -160,7 +168,7 @@ def main():
     dt = time.perf_counter() - t0
     st = vocab_h.stats()
 
-    t = torch.tensor([dt, float(nbytes)], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, float(nbytes)], dtype=torch.float64, device=cdev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -179,7 +187,8 @@ def main():
         achieved = avg_launch_bytes / 1e9 / (avg_launch_ms / 1e3) if avg_launch_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "radix_scatter_traffic.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and abs(nbytes - 100_000_000) < 1_000_000:
+            # PMC bytes per launch, collected separately (rocprofv3 --pmc) on this very workload
             with open(tfile) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         out = {
@@ -191,7 +200,8 @@ def main():
                        "sorted_depth": st["sorted_depth"], "symbol_bits": st["symbol_bits"],
                        "symbols_per_key": st["symbols_per_key"], "active_per_round": st["active_per_round"],
                        "radix_launches_per_step": radix_launches // max(args.steps, 1),
-                       "id_gather": "rccl gather to rank 0" if world > 1 else "none (single GPU)"},
+                       "id_gather": ("%s gather to rank 0" % ("rccl" if backend == "nccl" else backend)) if world > 1
+                       else "none (single GPU)"},
             "roofline": {"bound": "hbm", "kernel": "radix_scatter_kernel<uint64>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 4),

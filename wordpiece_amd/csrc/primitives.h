@@ -46,6 +46,14 @@ __device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
   return v;
 }
 
+// Workgroup barrier that only orders LDS traffic.  __syncthreads() also waits for the wave's
+// outstanding global stores (vmcnt(0)), which costs a memory round trip per loop iteration in the
+// single-workgroup "spine" loops that store a result and then reuse LDS scratch.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // ---- block-level (kBlock = 256 threads = 4 waves) -----------------------------------------
 // Exclusive sum over the block; `total` = block sum.  smem: >= 8 uint32.
 __device__ __forceinline__ uint32_t block_excl_sum(uint32_t v, uint32_t *smem, uint32_t &total) {

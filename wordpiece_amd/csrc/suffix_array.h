@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kRrSpineThreads) void rerank_spine_kernel(RerankAgg
       wh[w] = ih;
       wm[w] = im;
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t ba = ca, bh = ch, bm = cm, ta = 0, th = 0, tm = 0;
 #pragma unroll
     for (int q = 0; q < WAVES; q++) {
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kRrSpineThreads) void rerank_spine_kernel(RerankAgg
     ca += ta;
     ch += th;
     cm = max(cm, tm);
-    __syncthreads();
+    lds_barrier();
   }
   if (threadIdx.x == 0) {
     totals[0] = ca;
