@@ -82,6 +82,9 @@ int wp_linear_encode_external(const char *text_file, const char *vocab_file, con
 #define WP_OPT_STAGE_TIMING 4 /* 1: record per-stage device times with HIP events */
 #define WP_OPT_LCP_KASAI 5    /* 1: build LCP with the chunked Kasai kernel (linear.cpp:18-70)
                                  instead of deriving it inside the doubling rounds */
+#define WP_OPT_FUSED_RERANK 6 /* 1: single-pass group split (chained scan across tiles) instead of
+                                 the default count / spine / apply kernels; same results, same
+                                 speed on MI355X ("measured dead ends") */
 int wp_set_option(wp_vocab *v, int option, int64_t value);
 
 /* ---- statistics of the last encode on this handle (for bench.py / roofline) ---- */

@@ -1,0 +1,63 @@
+"""Derives profiles/radix_scatter_traffic.json from the two rocprofv3 --pmc passes of collect.sh.
+
+usage: python profiles/make_traffic_json.py <dir with *_pmc_FETCH_SIZE/ and *_pmc_WRITE_SIZE/> <tag>
+FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 FETCH_SIZE tallies 128-B requests as 64 B, so it is doubled
+(MI355X_MICROARCH.md, HBM section).  The factor is checked on radix_hist_kernel<uint64>, which reads exactly
+8 B per key and nothing else.  Bytes are summed over all launches of one bench step and divided by the
+launch count, like bench.py's `achieved`.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+base, tag = sys.argv[1], sys.argv[2]
+KEY = "radix_scatter_kernel<unsigned long>"
+HIST = "radix_hist_kernel<unsigned long>"
+
+
+def per_kernel(counter):
+    f = glob.glob(os.path.join(base, "%s_pmc_%s" % (tag, counter), "*counter_collection.csv"))[0]
+    tot, cnt, grid = collections.Counter(), collections.Counter(), {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"]
+        tot[k] += float(r["Counter_Value"]) * 1024.0
+        cnt[k] += 1
+        grid.setdefault(k, []).append(int(r["Grid_Size"]))
+    return tot, cnt, grid
+
+
+ft, fc, fg = per_kernel("FETCH_SIZE")
+wt, wc, _ = per_kernel("WRITE_SIZE")
+name = [k for k in ft if KEY in k][0]
+hist = [k for k in ft if HIST in k][0]
+# bench.py --steps 1 --warmup 1 encodes twice (+ once more for the oracle sample check): per-launch
+# averages do not depend on the number of steps
+launches = fc[name]
+# hist kernel: one workgroup (256 threads) per tile of 20*256 keys -> keys = grid/256*5120 (upper bound)
+hist_known = sum(g / 256 * 5120 * 8 for g in fg[hist])
+factor = hist_known / ft[hist]
+fetch = 2.0 * ft[name] / launches
+write = wt[name] / wc[name]
+bench = json.load(open(os.path.join(base, "%s_bench.json" % tag)))
+alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+out = {
+    "kernel": "radix_scatter_kernel<uint64>",
+    "round": tag,
+    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 "
+              "--warmup 1 --no-cpu-baseline` (profiles/collect.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md "
+              "(gfx950 tallies 128-B requests as 64 B); WRITE_SIZE taken as is",
+    "fetch_factor_check_on_radix_hist": round(factor, 3),
+    "launches_counted": launches,
+    "fetch_bytes_per_launch": int(fetch),
+    "write_bytes_per_launch": int(write),
+    "hbm_bytes_per_launch": int(fetch + write),
+    "algorithmic_bytes_per_launch": alg,
+    "ratio": round((fetch + write) / alg, 3),
+}
+print(json.dumps(out, indent=1))
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "radix_scatter_traffic.json"), "w"), indent=1)

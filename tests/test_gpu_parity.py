@@ -35,11 +35,13 @@ def _combine(d, vocab_lens, which):
     return out.astype(np.int32)
 
 
-def check_all_stages(text, vocab, label=""):
+def check_all_stages(text, vocab, label="", fused=False):
     text = text if isinstance(text, bytes) else text.encode("utf8")
     ov = O.Vocab(vocab)
     d = ov.encode_debug(text)
     gv = W.Vocab(vocab)
+    if fused:
+        gv.set_option(W.WP_OPT_FUSED_RERANK, 1)
     gv.set_option(W.WP_OPT_FULL_DEPTH, 1)
     gv.set_option(W.WP_OPT_KEEP_DEBUG, 1)  # keeps the raw code points for debug_fetch(6)
     ids = gv.encode(text)
@@ -150,6 +152,27 @@ def test_duplicate_vocab_lines_force_full_depth():
     v = W.Vocab(["ab", "x", "ab"])
     assert v.encode("ab ab").tolist() == [0, 0]
     assert v.stats()["full_depth"] == 1
+
+
+def test_fused_rerank_all_stages():
+    """WP_OPT_FUSED_RERANK (single-pass group split): every intermediate array equals the oracle's."""
+    text, vocab = synth.english_corpus(1_000_000, seed=33, vocab_size=4000)
+    check_all_stages(text, vocab, "fused 1MB", fused=True)
+    text, vocab = synth.deep_prefix_corpus(300_000, seed=5, word_len=128, n_stems=16, suffix_stems=4, suffix_len=32)
+    check_all_stages(text, vocab, "fused deep", fused=True)
+    check_all_stages(b"", ["a"], "fused empty", fused=True)
+    check_all_stages("ab ab", ["ab", "x", "ab"], "fused dup", fused=True)
+
+
+def test_fused_rerank_deep_prefix_8mb_ids():
+    """Many doubling rounds over a large list: the deferred group-depth stores of the fused split
+    (suffix_array.h) must not be seen by tiles still computing depths."""
+    text, vocab = synth.deep_prefix_corpus(8_000_000, seed=14)
+    gv = W.Vocab(vocab)
+    gv.set_option(W.WP_OPT_FUSED_RERANK, 1)
+    ids = gv.encode(text)
+    assert gv.stats()["rounds"] >= 4
+    assert np.array_equal(ids, _oracle_ids_fast(text, vocab))
 
 
 def test_kasai_kernel_gives_same_lcp():

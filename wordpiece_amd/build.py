@@ -35,7 +35,8 @@ def build(force=False, verbose=False):
     deps = _deps()
     if force or _newer(LIB, deps):
         cmd = [hipcc, "-O3", "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-function", "-x", "hip", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+               "-Wno-unused-function"] + os.environ.get("WP_HIPCC_FLAGS", "").split() + [
+               "-x", "hip", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

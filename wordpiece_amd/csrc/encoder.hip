@@ -115,7 +115,7 @@ struct wp_vocab {
   HostVocab hv;
   std::unique_ptr<Context> ctx;
   int device = -1;
-  bool full_depth = false, keep_debug = false, stage_timing = false, lcp_kasai = false;
+  bool full_depth = false, keep_debug = false, stage_timing = false, lcp_kasai = false, fused_rerank = false;
   wp_stats stats{};
   ~wp_vocab();
 };
@@ -335,7 +335,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     d_rank = ar.take<RankEntry>(n);
     AD0 = ar.take<uint32_t>(n);
     AD1 = ar.take<uint32_t>(n);
-    d_tdep = ar.take<uint32_t>(n);
+    d_tdep = ar.take<uint32_t>(n + 2 + rr_tiles * 4 + 8);  // (tail: look-back state of the fused rerank)
     d_gdepth = ar.take<uint32_t>(n);
     d_lcp = ar.take<int32_t>(n);
     d_radix_tmp = ar.take<uint32_t>(radix_words);
@@ -462,19 +462,37 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     hipLaunchKernelGGL(anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls, n_text, d_anchor_cnt,
                        d_anchors);
   }
+  // group split of a round: count / spine / apply kernels, or (WP_OPT_FUSED_RERANK, env WP_RERANK=fused)
+  // one kernel with a chained scan across tiles
+  static const bool env_fused = getenv("WP_RERANK") && std::strcmp(getenv("WP_RERANK"), "fused") == 0;
+  const bool fused_rerank = v->fused_rerank || env_fused;
+  LookbackState lb;  // lives behind the tdep buffer
   {
     const unsigned tiles = cdiv(n, kRrTile);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<true>), dim3(tiles), dim3(kBlock), 0, st, keys, vals, n,
-                       static_cast<const uint32_t *>(nullptr), static_cast<const RankEntry *>(nullptr),
-                       static_cast<const uint32_t *>(nullptr), n, dcode.first_len, dcode.uniform_bits, rule, d_tdep,
-                       d_agg);
-    hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kRrSpineThreads), 0, st, d_agg, static_cast<size_t>(tiles),
-                       c->d_scalars + 4, d_ghead);
+    lb.wa = reinterpret_cast<unsigned long long *>(d_tdep + ((n + 1) & ~static_cast<size_t>(1)));
+    lb.wb = lb.wa + tiles;
+    lb.ticket = reinterpret_cast<uint32_t *>(lb.wb + tiles);
+    const size_t lb_bytes = static_cast<size_t>(tiles) * 16 + 16;
     RankEntry *hd = reinterpret_cast<RankEntry *>(cur ? K0 : K1);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
-                       vals, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), d_tdep, n,
-                       d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp, slots, other_vals,
-                       AG, adep, d_ghead, d_gdepth);
+    if (fused_rerank) {
+      WP_HIP(hipMemsetAsync(lb.wa, 0, lb_bytes, st));
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_fused_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
+                         vals, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), n, tiles,
+                         lb, d_sym, static_cast<const RankEntry *>(nullptr), static_cast<const uint32_t *>(nullptr), n,
+                         dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp, slots, other_vals, AG, adep,
+                         d_ghead, d_gdepth, static_cast<uint32_t *>(nullptr), c->d_scalars + 4);
+    } else {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<true>), dim3(tiles), dim3(kBlock), 0, st, keys, vals, n,
+                         static_cast<const uint32_t *>(nullptr), static_cast<const RankEntry *>(nullptr),
+                         static_cast<const uint32_t *>(nullptr), n, dcode.first_len, dcode.uniform_bits, rule, d_tdep,
+                         d_agg);
+      hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kRrSpineThreads), 0, st, d_agg,
+                         static_cast<size_t>(tiles), c->d_scalars + 4, d_ghead);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
+                         vals, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), d_tdep,
+                         n, d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp, slots,
+                         other_vals, AG, adep, d_ghead, d_gdepth);
+    }
     fork();
     store_ranks(vals, hd, reinterpret_cast<uint32_t *>(hd) + n, reinterpret_cast<uint32_t *>(keys), n);
     WP_LAUNCH_CHECK();
@@ -510,14 +528,26 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       join();
     }
     const unsigned tiles = cdiv(n_act, kRrTile);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<false>), dim3(tiles), dim3(kBlock), 0, st, skeys, svals,
-                       n_act, adep, d_rank, d_gdepth, n, dcode.first_len, dcode.uniform_bits, rule, d_tdep, d_agg);
-    hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kRrSpineThreads), 0, st, d_agg, static_cast<size_t>(tiles),
-                       c->d_scalars + 4, d_ghead);
     RankEntry *hd = reinterpret_cast<RankEntry *>(kfree);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
-                       svals, slots, adep, d_tdep, n_act, d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule,
-                       d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead, d_gdepth);
+    if (fused_rerank) {
+      WP_HIP(hipMemsetAsync(lb.wa, 0, static_cast<size_t>(tiles) * 16 + 16, st));
+      lb.wb = lb.wa + tiles;
+      lb.ticket = reinterpret_cast<uint32_t *>(lb.wb + tiles);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_fused_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
+                         svals, slots, adep, n_act, tiles, lb, d_sym, d_rank, d_gdepth, n, dcode.first_len,
+                         dcode.uniform_bits, rule, d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead,
+                         d_gdepth, d_tdep, c->d_scalars + 4);
+      hipLaunchKernelGGL(gdepth_store_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, d_tdep, slots, n_act,
+                         d_gdepth);
+    } else {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<false>), dim3(tiles), dim3(kBlock), 0, st, skeys, svals,
+                         n_act, adep, d_rank, d_gdepth, n, dcode.first_len, dcode.uniform_bits, rule, d_tdep, d_agg);
+      hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kRrSpineThreads), 0, st, d_agg,
+                         static_cast<size_t>(tiles), c->d_scalars + 4, d_ghead);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
+                         svals, slots, adep, d_tdep, n_act, d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule,
+                         d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead, d_gdepth);
+    }
     fork();
     store_ranks(svals, hd, reinterpret_cast<uint32_t *>(hd) + n, reinterpret_cast<uint32_t *>(skeys), n_act);
     WP_LAUNCH_CHECK();
@@ -739,6 +769,7 @@ int wp_set_option(wp_vocab *v, int option, int64_t value) {
     case WP_OPT_KEEP_DEBUG: v->keep_debug = value != 0; return WP_OK;
     case WP_OPT_STAGE_TIMING: v->stage_timing = value != 0; return WP_OK;
     case WP_OPT_LCP_KASAI: v->lcp_kasai = value != 0; return WP_OK;
+    case WP_OPT_FUSED_RERANK: v->fused_rerank = value != 0; return WP_OK;
   }
   g_last_error = "unknown option";
   return WP_ERR_ARG;

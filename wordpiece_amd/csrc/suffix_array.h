@@ -339,6 +339,225 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
   }
 }
 
+// ---- single-pass rerank: the two passes above fused with a chained scan --------------------------
+// The split of a round needs, per tile of the list, the exclusive prefix of three scalars (entries
+// that stay active, their group heads, position of the last group head).  Here every workgroup takes
+// a tile ticket (so all lower tiles are running or done), publishes its three scalars as an
+// AGGREGATE, looks back over its predecessors 64 tiles per step (one wave, one predecessor per
+// lane) until it meets an INCLUSIVE prefix, publishes its own INCLUSIVE prefix and carries on with
+// the apply pass — no separate counting pass over the keys, no spine kernel, no tdep round trip.
+// A tile's state is two 64-bit words written/read with relaxed agent-scope atomics (flag and value
+// in one word); a reader only accepts a tile whose two words carry the same flag.
+constexpr uint64_t kLbAgg = 1ull << 62, kLbIncl = 2ull << 62, kLbFlagMask = 3ull << 62;
+
+struct LookbackState {
+  unsigned long long *wa;  // flag | n_active (31 bits) << 31 | n_heads (31 bits)
+  unsigned long long *wb;  // flag | last_flag (32 bits)
+  uint32_t *ticket;
+};
+
+template <typename SymT, bool ROUND0>
+__global__ __launch_bounds__(kBlock) void rerank_fused_kernel(
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ slots,
+    const uint32_t *__restrict__ adep, size_t m, unsigned tiles, LookbackState lb, const SymT *__restrict__ sym,
+    const RankEntry *__restrict__ rd, const uint32_t *__restrict__ gdepth_in, size_t n,
+    const uint8_t *__restrict__ first_len, int uniform_bits, DepthRule rule, uint32_t *__restrict__ sa,
+    RankEntry *__restrict__ hd, int32_t *__restrict__ lcp, uint32_t *__restrict__ nslots,
+    uint32_t *__restrict__ nvals, uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep,
+    uint32_t *__restrict__ ghead, uint32_t *__restrict__ gdepth, uint32_t *__restrict__ gd,
+    uint32_t *__restrict__ totals) {
+  __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
+  __shared__ uint32_t s_tile, s_pre[3];
+  __shared__ uint8_t s_fl[kDecodeTableBytes];
+  if (ROUND0 && !uniform_bits) {
+    for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
+      reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
+    }
+  }
+  if (threadIdx.x == 0) s_tile = atomicAdd(lb.ticket, 1u);
+  __syncthreads();
+  const unsigned tile = s_tile;
+  const int lane = lane_id(), w = wave_id();
+  const size_t wave_base = static_cast<size_t>(tile) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
+  const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+
+  // ---- phase 1: flags, new depths (kept in registers), tile counts
+  uint64_t bfs[kRrRounds], bas[kRrRounds], bhs[kRrRounds];
+  uint32_t nds[kRrRounds];
+  uint32_t na = 0, nh = 0, last = 0;
+#pragma unroll
+  for (int r = 0; r < kRrRounds; r++) {
+    const size_t k = wave_base + static_cast<size_t>(r) * kWave + lane;
+    bool f = false, sg = true, act = false;
+    uint32_t nd = 0;
+    if (k < m) {
+      rr_flags(keys, m, k, f, sg);
+      if (!sg) {
+        if (ROUND0) {
+          nd = static_cast<uint32_t>(count_key_symbols(keys[k], kKeyBits, s_fl, uniform_bits));
+        } else {
+          const uint32_t d = adep[k];
+          const size_t t = static_cast<size_t>(vals[k]) + d;
+          const uint32_t dj = t < n ? gdepth_in[rd[t]] : 0u;
+          nd = min(d + dj, 0x7fffffffu);
+        }
+        act = rule.full || nd < rule.need;
+      }
+    }
+    nds[r] = nd;
+    bfs[r] = __ballot(f);
+    bas[r] = __ballot(act);
+    bhs[r] = __ballot(f && act);
+    na += __popcll(bas[r]);
+    nh += __popcll(bhs[r]);
+    if (bfs[r]) last = static_cast<uint32_t>(wave_base + static_cast<size_t>(r) * kWave + (63 - __clzll(static_cast<long long>(bfs[r]))) + 1);
+  }
+  if (lane == 0) {
+    s_na[w] = na;
+    s_nh[w] = nh;
+    s_last[w] = last;
+  }
+  __syncthreads();
+
+  // ---- chained scan (wave 0): publish AGGREGATE, look back, publish INCLUSIVE
+  if (w == 0) {
+    const uint32_t ta = s_na[0] + s_na[1] + s_na[2] + s_na[3];
+    const uint32_t th = s_nh[0] + s_nh[1] + s_nh[2] + s_nh[3];
+    const uint32_t tl = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+    if (lane == 0 && tile > 0) {
+      __hip_atomic_store(&lb.wa[tile], kLbAgg | (static_cast<uint64_t>(ta) << 31) | th, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&lb.wb[tile], kLbAgg | tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint64_t ea = 0, eh = 0;
+    uint32_t em = 0;
+    long long t = static_cast<long long>(tile) - 1;
+    while (t >= 0) {
+      const long long mine = t - lane;
+      uint64_t va = 0, vb = 0;
+      bool ok = true;  // lanes past tile 0 count as ready and contribute nothing
+      if (mine >= 0) {
+        va = __hip_atomic_load(&lb.wa[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vb = __hip_atomic_load(&lb.wb[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = (va & kLbFlagMask) != 0 && (va & kLbFlagMask) == (vb & kLbFlagMask);
+      }
+      const bool incl = mine >= 0 && ok && (va & kLbFlagMask) == kLbIncl;
+      const uint64_t bincl = __ballot(incl);
+      // lanes needed: all up to (and including) the nearest INCLUSIVE one, else the whole window
+      const int upto = bincl ? __ffsll(static_cast<long long>(bincl)) - 1 : kWave - 1;
+      const uint64_t need = upto == 63 ? ~0ull : ((1ull << (upto + 1)) - 1ull);
+      const uint64_t bok = __ballot(ok);
+      if ((bok & need) != need) {  // some needed predecessor has not published yet
+        __builtin_amdgcn_s_sleep(2);
+        continue;
+      }
+      const bool use = lane <= upto && mine >= 0;
+      uint64_t ca = use ? ((va >> 31) & 0x7fffffffull) : 0ull, ch = use ? (va & 0x7fffffffull) : 0ull;
+      uint32_t cm = use ? static_cast<uint32_t>(vb) : 0u;
+#pragma unroll
+      for (int d = kWave / 2; d > 0; d >>= 1) {
+        ca += __shfl_xor(ca, d, kWave);
+        ch += __shfl_xor(ch, d, kWave);
+        cm = max(cm, static_cast<uint32_t>(__shfl_xor(cm, d, kWave)));
+      }
+      ea += ca;
+      eh += ch;
+      em = max(em, cm);
+      if (bincl) break;
+      t -= kWave;
+    }
+    if (lane == 0) {
+      __hip_atomic_store(&lb.wa[tile], kLbIncl | ((ea + ta) << 31) | (eh + th), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&lb.wb[tile], kLbIncl | max(em, tl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_pre[0] = static_cast<uint32_t>(ea);
+      s_pre[1] = static_cast<uint32_t>(eh);
+      s_pre[2] = em;
+      if (tile + 1 == tiles) {  // the last tile knows the totals of the round
+        totals[0] = static_cast<uint32_t>(ea + ta);
+        totals[1] = static_cast<uint32_t>(eh + th);
+        ghead[eh + th] = static_cast<uint32_t>(ea + ta);  // sentinel of the next list's group table
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t ea = s_pre[0], eh = s_pre[1], head1 = s_pre[2];  // head1: 1-based list index
+  for (int i = 0; i < w; i++) {
+    ea += s_na[i];
+    eh += s_nh[i];
+    head1 = max(head1, s_last[i]);
+  }
+
+  // ---- phase 2: apply (same as rerank_apply_kernel)
+#pragma unroll
+  for (int r = 0; r < kRrRounds; r++) {
+    const size_t round_base = wave_base + static_cast<size_t>(r) * kWave;
+    const size_t k = round_base + lane;
+    const uint64_t bf = bfs[r], ba = bas[r], bh = bhs[r];
+    if (k < m) {
+      const uint64_t mine = bf & le;
+      const size_t head = mine ? round_base + (63 - __clzll(static_cast<long long>(mine)))
+                               : (head1 ? static_cast<size_t>(head1) - 1 : 0);
+      const bool f = (bf >> lane) & 1ull;
+      const bool act = (ba >> lane) & 1ull;
+      const uint32_t v = vals[k];
+      const uint32_t x = ROUND0 ? static_cast<uint32_t>(k) : slots[k];
+      const uint32_t head_slot = ROUND0 ? static_cast<uint32_t>(head) : slots[head];
+      const uint64_t me = keys[k];
+      const bool single = f && (k + 1 == m || keys[k + 1] != me);
+      if (sa) sa[x] = v;
+      bool changed = true;
+      if (!ROUND0) changed = head > 0 && (keys[head] >> 32) == (keys[head - 1] >> 32);
+      const uint32_t nd = single ? 0u : nds[r];
+      hd[k] = changed ? head_slot : kRankUnchanged;
+      // Rounds >= 1: tiles still in phase 1 read the OLD depths through gdepth_in, so the new depth
+      // of a group head is parked in gd[] and stored by gdepth_store_kernel after this launch.
+      if (ROUND0) {
+        if (f && !single) gdepth[x] = nd;
+      } else {
+        gd[k] = (f && !single) ? nd : kRankUnchanged;
+      }
+      if (ROUND0) {
+        if (k > 0) {
+          int32_t l = -1;
+          if (f) {
+            const uint64_t d = me ^ keys[k - 1];
+            l = count_key_symbols(me, __clzll(static_cast<long long>(d)) - (64 - kKeyBits), s_fl, uniform_bits);
+          }
+          lcp[x - 1] = l;
+        }
+      } else if (f && k > 0 && (me >> 32) == (keys[k - 1] >> 32)) {
+        const uint32_t d = adep[k];
+        lcp[x - 1] = static_cast<int32_t>(d)
+                     + lcp_compare(sym, n, static_cast<size_t>(vals[k - 1]) + d, static_cast<size_t>(v) + d,
+                                   0x7fffffff);
+      }
+      if (act) {
+        const uint32_t pos = ea + __popcll(ba & lt);
+        const uint32_t g = eh + __popcll(bh & le) - 1;
+        nslots[pos] = x;
+        nvals[pos] = v;
+        ngid[pos] = g;
+        ndep[pos] = nd;
+        if (f) ghead[g] = pos;
+      }
+    }
+    ea += __popcll(ba);
+    eh += __popcll(bh);
+    if (bf) head1 = static_cast<uint32_t>(round_base + (63 - __clzll(static_cast<long long>(bf))) + 1);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gdepth_store_kernel(const uint32_t *__restrict__ gd,
+                                                              const uint32_t *__restrict__ slots, size_t m,
+                                                              uint32_t *__restrict__ gdepth) {
+  const size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (k < m) {
+    const uint32_t v = gd[k];
+    if (v != kRankUnchanged) gdepth[slots[k]] = v;
+  }
+}
+
 // ---- chunked Kasai (linear.cpp:18-41), optional alternative LCP builder --------------------
 // One thread per chunk of consecutive text positions, restarting with prefix_len = 0 exactly
 // as the reference's per-thread chunks do.  Needs the full-depth SA (rank is a permutation).
