@@ -313,7 +313,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
            *d_midx1 = nullptr, *d_minfo = nullptr, *d_tile_mlo = nullptr, *d_emit_cnt = nullptr,
            *d_emit_tmp = nullptr;
   int32_t *d_lcp = nullptr, *d_mid = nullptr, *d_rf = nullptr, *d_rb = nullptr;
-  RerankAgg *d_agg = nullptr;
+  RerankAgg *d_agg = nullptr, *d_chunk_agg = nullptr;
   uint32_t *d_ghead = nullptr, *d_large_id = nullptr, *d_large_off = nullptr, *d_gscan_tmp = nullptr, *LV0 = nullptr,
            *LV1 = nullptr, *LPOS = nullptr;
   uint64_t *LK1 = nullptr;
@@ -348,6 +348,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     LV1 = ar.take<uint32_t>(n);
     LPOS = ar.take<uint32_t>(n);
     d_agg = ar.take<RerankAgg>(rr_tiles + 1);
+    d_chunk_agg = ar.take<RerankAgg>(cdiv(rr_tiles, kRrChunk) + 1);
     d_mslot0 = ar.take<uint32_t>(M + 1);
     d_mslot1 = ar.take<uint32_t>(M + 1);
     d_midx0 = ar.take<uint32_t>(M + 1);
@@ -455,7 +456,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     // side stream: the anchor list and the cleared emit array only need the class bytes; they run
     // next to the (gather/scatter bound) rerank kernels rather than next to the streaming radix passes
     fork();
-    const unsigned atiles = cdiv(n_text, kScanTile);
+    const unsigned atiles = cdiv(n_text, kAnchorTile);
     WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st2));
     hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls, n_text, d_anchor_cnt);
     device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st2);
@@ -486,12 +487,12 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                          static_cast<const uint32_t *>(nullptr), static_cast<const RankEntry *>(nullptr),
                          static_cast<const uint32_t *>(nullptr), n, dcode.first_len, dcode.uniform_bits, rule, d_tdep,
                          d_agg);
-      hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kRrSpineThreads), 0, st, d_agg,
-                         static_cast<size_t>(tiles), c->d_scalars + 4, d_ghead);
+      hipLaunchKernelGGL(rerank_chunk_kernel, dim3(cdiv(tiles, kRrChunk)), dim3(kBlock), 0, st, d_agg, tiles,
+                         d_chunk_agg);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
                          vals, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), d_tdep,
-                         n, d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp, slots,
-                         other_vals, AG, adep, d_ghead, d_gdepth);
+                         n, d_agg, d_chunk_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp,
+                         slots, other_vals, AG, adep, d_ghead, d_gdepth, c->d_scalars + 4);
     }
     fork();
     store_ranks(vals, hd, reinterpret_cast<uint32_t *>(hd) + n, reinterpret_cast<uint32_t *>(keys), n);
@@ -542,11 +543,12 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     } else {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<false>), dim3(tiles), dim3(kBlock), 0, st, skeys, svals,
                          n_act, adep, d_rank, d_gdepth, n, dcode.first_len, dcode.uniform_bits, rule, d_tdep, d_agg);
-      hipLaunchKernelGGL(rerank_spine_kernel, dim3(1), dim3(kRrSpineThreads), 0, st, d_agg,
-                         static_cast<size_t>(tiles), c->d_scalars + 4, d_ghead);
+      hipLaunchKernelGGL(rerank_chunk_kernel, dim3(cdiv(tiles, kRrChunk)), dim3(kBlock), 0, st, d_agg, tiles,
+                         d_chunk_agg);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
-                         svals, slots, adep, d_tdep, n_act, d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule,
-                         d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead, d_gdepth);
+                         svals, slots, adep, d_tdep, n_act, d_agg, d_chunk_agg, d_sym, n, dcode.first_len,
+                         dcode.uniform_bits, rule, d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead,
+                         d_gdepth, c->d_scalars + 4);
     }
     fork();
     store_ranks(svals, hd, reinterpret_cast<uint32_t *>(hd) + n, reinterpret_cast<uint32_t *>(skeys), n_act);

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
 // chunk_pre[chunk][d] = exclusive prefix of chunk_sums in (digit, chunk) order
 constexpr int kSpineThreads = 1024;
 constexpr int kSpineParts = kSpineThreads / kRadixBins;
+constexpr int kSpineBatch = 16;
 __global__ __launch_bounds__(kSpineThreads) void radix_spine_kernel(const uint32_t *__restrict__ chunk_sums,
                                                                     uint32_t *__restrict__ chunk_pre,
                                                                     unsigned nchunks) {
@@ -135,8 +136,15 @@ __global__ __launch_bounds__(kSpineThreads) void radix_spine_kernel(const uint32
   const int d = threadIdx.x & (kRadixBins - 1), q = threadIdx.x / kRadixBins;
   const unsigned per = (nchunks + kSpineParts - 1) / kSpineParts;
   const unsigned c0 = min(nchunks, q * per), c1 = min(nchunks, c0 + per);
+  // (loads issued kSpineBatch at a time: the loops are latency bound, one row per iteration)
   uint32_t sum = 0;
-  for (unsigned c = c0; c < c1; c++) sum += chunk_sums[static_cast<size_t>(c) * kRadixBins + d];
+  for (unsigned c = c0; c < c1; c += kSpineBatch) {
+    uint32_t v[kSpineBatch];
+#pragma unroll
+    for (int j = 0; j < kSpineBatch; j++) v[j] = c + j < c1 ? chunk_sums[static_cast<size_t>(c + j) * kRadixBins + d] : 0u;
+#pragma unroll
+    for (int j = 0; j < kSpineBatch; j++) sum += v[j];
+  }
   part[q][d] = sum;
   __syncthreads();
   uint32_t before = 0, total = 0;
@@ -157,10 +165,15 @@ __global__ __launch_bounds__(kSpineThreads) void radix_spine_kernel(const uint32
   }
   __syncthreads();
   uint32_t run = part[0][d] + before;
-  for (unsigned c = c0; c < c1; c++) {
-    const size_t i = static_cast<size_t>(c) * kRadixBins + d;
-    chunk_pre[i] = run;
-    run += chunk_sums[i];
+  for (unsigned c = c0; c < c1; c += kSpineBatch) {
+    uint32_t v[kSpineBatch];
+#pragma unroll
+    for (int j = 0; j < kSpineBatch; j++) v[j] = c + j < c1 ? chunk_sums[static_cast<size_t>(c + j) * kRadixBins + d] : 0u;
+#pragma unroll
+    for (int j = 0; j < kSpineBatch; j++) {
+      if (c + j < c1) chunk_pre[static_cast<size_t>(c + j) * kRadixBins + d] = run;
+      run += v[j];
+    }
   }
 }
 
@@ -170,11 +183,15 @@ __global__ __launch_bounds__(kRadixBins) void radix_apply_kernel(uint32_t *__res
   const int d = threadIdx.x;
   const unsigned t0 = blockIdx.x * kColChunk, t1 = min(ntiles, t0 + kColChunk);
   uint32_t run = chunk_pre[static_cast<size_t>(blockIdx.x) * kRadixBins + d];
-  for (unsigned t = t0; t < t1; t++) {
-    const size_t i = static_cast<size_t>(t) * kRadixBins + d;
-    const uint32_t v = table[i];
-    table[i] = run;
-    run += v;
+  for (unsigned t = t0; t < t1; t += kSpineBatch) {
+    uint32_t v[kSpineBatch];
+#pragma unroll
+    for (int j = 0; j < kSpineBatch; j++) v[j] = t + j < t1 ? table[static_cast<size_t>(t + j) * kRadixBins + d] : 0u;
+#pragma unroll
+    for (int j = 0; j < kSpineBatch; j++) {
+      if (t + j < t1) table[static_cast<size_t>(t + j) * kRadixBins + d] = run;
+      run += v[j];
+    }
   }
 }
 
@@ -325,11 +342,13 @@ struct RadixStats {
   EventSpans spans;  // around every scatter launch
 };
 
+constexpr int kMaxZeroedPasses = 8;  // chunk-sum tables cleared by one memset per sort
+
 template <typename KeyT>
 size_t radix_tmp_words(size_t n) {
   size_t ntiles = cdiv(n, RadixCfg<KeyT>::kTile);
   size_t h = ntiles * kRadixBins;
-  return h + 2 * (cdiv(ntiles, kColChunk) + 1) * kRadixBins + 64;
+  return h + (kMaxZeroedPasses + 1) * (cdiv(ntiles, kColChunk) + 1) * kRadixBins + 64;
 }
 
 struct BitRange {
@@ -347,14 +366,19 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
   const unsigned ntiles = cdiv(n, RadixCfg<KeyT>::kTile);
   const unsigned nchunks = cdiv(ntiles, kColChunk);
   const size_t h = static_cast<size_t>(ntiles) * kRadixBins;
-  uint32_t *table = tmp, *chunk_sums = tmp + h;
-  uint32_t *chunk_pre = chunk_sums + static_cast<size_t>(nchunks + 1) * kRadixBins;
+  const size_t cs_words = static_cast<size_t>(nchunks + 1) * kRadixBins;
+  uint32_t *table = tmp, *chunk_pre = tmp + h, *chunk_sums0 = chunk_pre + cs_words;
+  // every pass adds into its own chunk-sum table; the first kMaxZeroedPasses are cleared at once
+  WP_HIP(hipMemsetAsync(chunk_sums0, 0, sizeof(uint32_t) * cs_words * kMaxZeroedPasses, st));
+  int pass = 0;
   for (int r = 0; r < nranges; r++) {
     for (int b = ranges[r].begin; b < ranges[r].end; b += kRadixBits) {
       const uint32_t mask = (1u << min(kRadixBits, ranges[r].end - b)) - 1u;
       KeyT *ki = cur ? k1 : k0, *ko = cur ? k0 : k1;
       uint32_t *vi = cur ? v1 : v0, *vo = cur ? v0 : v1;
-      WP_HIP(hipMemsetAsync(chunk_sums, 0, sizeof(uint32_t) * static_cast<size_t>(nchunks) * kRadixBins, st));
+      uint32_t *chunk_sums = chunk_sums0 + cs_words * static_cast<size_t>(pass % kMaxZeroedPasses);
+      if (pass >= kMaxZeroedPasses) WP_HIP(hipMemsetAsync(chunk_sums, 0, sizeof(uint32_t) * cs_words, st));
+      pass++;
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, n, b, mask,
                          table, chunk_sums);
       hipLaunchKernelGGL(radix_spine_kernel, dim3(1), dim3(kSpineThreads), 0, st, chunk_sums, chunk_pre, nchunks);

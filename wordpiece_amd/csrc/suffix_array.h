@@ -115,71 +115,64 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
   }
 }
 
-// single workgroup of 1024 threads: exclusive prefix over tiles (running max of last_flag, sums of
-// the counts); totals[0] = n_active, totals[1] = n_heads
-constexpr int kRrSpineThreads = 1024;
-__global__ __launch_bounds__(kRrSpineThreads) void rerank_spine_kernel(RerankAgg *__restrict__ agg, size_t tiles,
-                                                                       uint32_t *__restrict__ totals,
-                                                                       uint32_t *__restrict__ ghead) {
-  constexpr int WAVES = kRrSpineThreads / kWave;
-  __shared__ uint32_t wa[WAVES], wh[WAVES], wm[WAVES];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t ca = 0, ch = 0, cm = 0;  // carries: active, heads, running max of last_flag
-  RerankAgg nxt = {0, 0, 0};
-  if (threadIdx.x < tiles) nxt = agg[threadIdx.x];
-  for (size_t base = 0; base < tiles; base += kRrSpineThreads) {
-    const size_t i = base + threadIdx.x;
-    const RerankAgg a = nxt;  // loaded one iteration ahead: its latency hides behind the barriers
-    nxt = RerankAgg{0, 0, 0};
-    if (i + kRrSpineThreads < tiles) nxt = agg[i + kRrSpineThreads];
-    // inclusive scans inside the wave
-    uint32_t ia = a.n_active, ih = a.n_heads, im = a.last_flag;
+// The apply pass needs, per tile, the exclusive prefix of the tile aggregates (sums of the two
+// counts, running max of last_flag).  Two levels instead of a single-workgroup scan: a small kernel
+// reduces chunks of kRrChunk tiles, and every apply workgroup reduces the chunks before its own plus
+// the tiles before it inside its chunk (<= 2 * 256 L2-resident loads per workgroup) — no serial
+// spine, no extra dependency between launches.
+constexpr int kRrChunk = kBlock;
+
+__device__ __forceinline__ RerankAgg block_reduce_agg(RerankAgg a, uint32_t (*sm)[4]) {
 #pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const uint32_t ta = __shfl_up(ia, d, kWave), th = __shfl_up(ih, d, kWave), tm = __shfl_up(im, d, kWave);
-      if (lane >= d) {
-        ia += ta;
-        ih += th;
-        im = max(im, tm);
-      }
-    }
-    if (lane == kWave - 1) {
-      wa[w] = ia;
-      wh[w] = ih;
-      wm[w] = im;
-    }
-    lds_barrier();
-    uint32_t ba = ca, bh = ch, bm = cm, ta = 0, th = 0, tm = 0;
-#pragma unroll
-    for (int q = 0; q < WAVES; q++) {
-      if (q < w) {
-        ba += wa[q];
-        bh += wh[q];
-        bm = max(bm, wm[q]);
-      }
-      ta += wa[q];
-      th += wh[q];
-      tm = max(tm, wm[q]);
-    }
-    // exclusive values for this tile
-    const uint32_t pm = __shfl_up(im, 1, kWave);
-    if (i < tiles) {
-      RerankAgg o;
-      o.n_active = ba + ia - a.n_active;
-      o.n_heads = bh + ih - a.n_heads;
-      o.last_flag = lane == 0 ? bm : max(bm, pm);
-      agg[i] = o;
-    }
-    ca += ta;
-    ch += th;
-    cm = max(cm, tm);
-    lds_barrier();
+  for (int d = kWave / 2; d > 0; d >>= 1) {
+    a.n_active += __shfl_xor(a.n_active, d, kWave);
+    a.n_heads += __shfl_xor(a.n_heads, d, kWave);
+    a.last_flag = max(a.last_flag, static_cast<uint32_t>(__shfl_xor(a.last_flag, d, kWave)));
   }
-  if (threadIdx.x == 0) {
-    totals[0] = ca;
-    totals[1] = ch;
-    ghead[ch] = ca;  // sentinel: group g of the next list is [ghead[g], ghead[g+1])
+  const int w = wave_id();
+  __syncthreads();
+  if (lane_id() == 0) {
+    sm[0][w] = a.n_active;
+    sm[1][w] = a.n_heads;
+    sm[2][w] = a.last_flag;
   }
+  __syncthreads();
+  RerankAgg o;
+  o.n_active = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
+  o.n_heads = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+  o.last_flag = max(max(sm[2][0], sm[2][1]), max(sm[2][2], sm[2][3]));
+  return o;
+}
+
+__global__ __launch_bounds__(kBlock) void rerank_chunk_kernel(const RerankAgg *__restrict__ agg, unsigned tiles,
+                                                              RerankAgg *__restrict__ chunk_agg) {
+  __shared__ uint32_t sm[3][4];
+  const unsigned t = blockIdx.x * kRrChunk + threadIdx.x;
+  RerankAgg a = {0, 0, 0};
+  if (t < tiles) a = agg[t];
+  a = block_reduce_agg(a, sm);
+  if (threadIdx.x == 0) chunk_agg[blockIdx.x] = a;
+}
+
+// exclusive prefix of tile `tile` (all threads of the workgroup get it)
+__device__ __forceinline__ RerankAgg tile_prefix_agg(const RerankAgg *__restrict__ agg,
+                                                     const RerankAgg *__restrict__ chunk_agg, unsigned tile,
+                                                     uint32_t (*sm)[4]) {
+  const unsigned chunk = tile / kRrChunk, in_chunk = tile % kRrChunk;
+  RerankAgg a = {0, 0, 0};
+  for (unsigned c = threadIdx.x; c < chunk; c += kBlock) {
+    const RerankAgg v = chunk_agg[c];
+    a.n_active += v.n_active;
+    a.n_heads += v.n_heads;
+    a.last_flag = max(a.last_flag, v.last_flag);
+  }
+  if (threadIdx.x < in_chunk) {
+    const RerankAgg v = agg[chunk * kRrChunk + threadIdx.x];
+    a.n_active += v.n_active;
+    a.n_heads += v.n_heads;
+    a.last_flag = max(a.last_flag, v.last_flag);
+  }
+  return block_reduce_agg(a, sm);
 }
 
 // number of equal symbols at a+t, b+t for t < maxlen (positions >= n never match)
@@ -235,12 +228,13 @@ template <typename SymT, bool ROUND0>
 __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ slots,
     const uint32_t *__restrict__ adep, const uint32_t *__restrict__ tdep, size_t m,
-    const RerankAgg *__restrict__ agg, const SymT *__restrict__ sym, size_t n, const uint8_t *__restrict__ first_len,
-    int uniform_bits, DepthRule rule, uint32_t *__restrict__ sa, RankEntry *__restrict__ hd,
-    int32_t *__restrict__ lcp, uint32_t *__restrict__ nslots, uint32_t *__restrict__ nvals,
-    uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep, uint32_t *__restrict__ ghead,
-    uint32_t *__restrict__ gdepth) {
+    const RerankAgg *__restrict__ agg, const RerankAgg *__restrict__ chunk_agg, const SymT *__restrict__ sym, size_t n,
+    const uint8_t *__restrict__ first_len, int uniform_bits, DepthRule rule, uint32_t *__restrict__ sa,
+    RankEntry *__restrict__ hd, int32_t *__restrict__ lcp, uint32_t *__restrict__ nslots,
+    uint32_t *__restrict__ nvals, uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep,
+    uint32_t *__restrict__ ghead, uint32_t *__restrict__ gdepth, uint32_t *__restrict__ totals) {
   __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
+  __shared__ uint32_t s_red[3][4];
   __shared__ uint8_t s_fl[kDecodeTableBytes];
   if (ROUND0 && !uniform_bits) {
     for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
@@ -249,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
   }
   const int lane = lane_id(), w = wave_id();
   const size_t wave_base = static_cast<size_t>(blockIdx.x) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
-  const RerankAgg pre = agg[blockIdx.x];
+  const RerankAgg pre = tile_prefix_agg(agg, chunk_agg, blockIdx.x, s_red);
   const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
 
   uint64_t bfs[kRrRounds], bas[kRrRounds], bhs[kRrRounds];
@@ -275,6 +269,13 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     s_last[w] = last;
   }
   __syncthreads();
+  if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {  // the last tile knows the totals of the round
+    const uint32_t ta = pre.n_active + s_na[0] + s_na[1] + s_na[2] + s_na[3];
+    const uint32_t th = pre.n_heads + s_nh[0] + s_nh[1] + s_nh[2] + s_nh[3];
+    totals[0] = ta;
+    totals[1] = th;
+    ghead[th] = ta;  // sentinel: group g of the next list is [ghead[g], ghead[g+1])
+  }
   uint32_t ea = pre.n_active, eh = pre.n_heads, head1 = pre.last_flag;  // head1: 1-based list index
   for (int i = 0; i < w; i++) {
     ea += s_na[i];

@@ -74,52 +74,70 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
 // The walk is latency bound (about six dependent loads per token), and only one text position in
 // five is an anchor, so anchors are first compacted into a list: every lane of the walk kernel
 // then owns one anchor (= one word) and the waves are dense.
-__device__ __forceinline__ bool anchor_at(const uint8_t *__restrict__ cls, size_t p) {
-  const uint8_t c = cls[p];
-  if (c & kClsSpace) return false;
-  return p == 0 || w_hard(c) || w_hard(cls[p - 1]);
+// Both anchor kernels give every lane 16 consecutive class bytes (one 16-byte load) plus the byte in
+// front of them, and return the lane's anchors as a 16-bit mask.
+constexpr int kAnchorBytes = 16;
+constexpr int kAnchorTile = kBlock * kAnchorBytes;  // 4096 positions per workgroup
+
+__device__ __forceinline__ uint32_t anchor_mask16(const uint8_t *__restrict__ cls, size_t n, size_t i) {
+  if (i >= n) return 0u;
+  uint32_t w[4];
+  if (i + kAnchorBytes <= n) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(cls + i);  // cls is 256-byte aligned, i a multiple of 16
+    w[0] = v.x;
+    w[1] = v.y;
+    w[2] = v.z;
+    w[3] = v.w;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      w[q] = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const size_t p = i + 4 * q + j;
+        if (p < n) w[q] |= static_cast<uint32_t>(cls[p]) << (8 * j);
+      }
+    }
+  }
+  uint32_t space = 0, hard = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    // one bit per byte -> 4-bit field (byte j of the word -> bit j)
+    const uint32_t sp = w[q] & 0x01010101u;
+    const uint32_t hd = (w[q] >> 1) & ~(w[q] >> 2) & 0x01010101u;
+    space |= ((sp * 0x01020408u) >> 24) << (4 * q);
+    hard |= ((hd * 0x01020408u) >> 24) << (4 * q);
+  }
+  uint32_t before = 1u;  // position 0 counts as preceded by a hard boundary
+  if (i > 0) before = w_hard(cls[i - 1]) ? 1u : 0u;
+  uint32_t valid = 0xffffu;
+  if (i + kAnchorBytes > n) valid = (1u << (n - i)) - 1u;
+  return ~space & (hard | (hard << 1) | before) & valid;
 }
 
 __global__ __launch_bounds__(kBlock) void anchor_count_kernel(const uint8_t *__restrict__ cls, size_t n,
                                                               uint32_t *__restrict__ tile_counts) {
   __shared__ uint32_t sm[8];
-  const size_t base = static_cast<size_t>(blockIdx.x) * kScanTile;
-  uint32_t c = 0;
-#pragma unroll
-  for (int j = 0; j < kScanItems; j++) {
-    const size_t i = base + static_cast<size_t>(j) * kBlock + threadIdx.x;
-    if (i < n && anchor_at(cls, i)) c++;
-  }
+  const size_t i = static_cast<size_t>(blockIdx.x) * kAnchorTile + static_cast<size_t>(threadIdx.x) * kAnchorBytes;
+  const uint32_t c = __popc(anchor_mask16(cls, n, i));
   uint32_t tot;
   (void)block_excl_sum(c, sm, tot);
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
 }
 
-// wave-striped so that the list stays in text order and the stores are coalesced
+// the list stays in text order: lane offsets come from a workgroup scan of the per-lane counts
 __global__ __launch_bounds__(kBlock) void anchor_write_kernel(const uint8_t *__restrict__ cls, size_t n,
                                                               const uint32_t *__restrict__ tile_prefix,
                                                               uint32_t *__restrict__ anchors) {
-  __shared__ uint32_t wtot[4];
-  const int lane = lane_id(), w = wave_id();
-  const size_t wave_base = static_cast<size_t>(blockIdx.x) * kScanTile + static_cast<size_t>(w) * (kScanTile / 4);
-  uint64_t bal[kScanItems];
-  uint32_t cnt = 0;
-#pragma unroll
-  for (int r = 0; r < kScanItems; r++) {
-    const size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
-    bal[r] = __ballot(i < n && anchor_at(cls, i));
-    cnt += __popcll(bal[r]);
-  }
-  if (lane == 0) wtot[w] = cnt;
-  __syncthreads();
-  uint32_t o = tile_prefix[blockIdx.x];
-  for (int i = 0; i < w; i++) o += wtot[i];
-  const uint64_t lt = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int r = 0; r < kScanItems; r++) {
-    const size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
-    if ((bal[r] >> lane) & 1ull) anchors[o + __popcll(bal[r] & lt)] = static_cast<uint32_t>(i);
-    o += __popcll(bal[r]);
+  __shared__ uint32_t sm[8];
+  const size_t i = static_cast<size_t>(blockIdx.x) * kAnchorTile + static_cast<size_t>(threadIdx.x) * kAnchorBytes;
+  uint32_t m = anchor_mask16(cls, n, i);
+  uint32_t tot;
+  uint32_t o = tile_prefix[blockIdx.x] + block_excl_sum(static_cast<uint32_t>(__popc(m)), sm, tot);
+  while (m) {
+    const int j = __ffs(static_cast<int>(m)) - 1;
+    m &= m - 1;
+    anchors[o++] = static_cast<uint32_t>(i + j);
   }
 }
 
