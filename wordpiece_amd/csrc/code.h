@@ -27,7 +27,7 @@ struct SymbolCode {
   std::vector<uint16_t> cw;        // codeword of dense symbol s (0 = past-the-end padding), right aligned
   std::vector<uint8_t> len;        // its length in bits
   std::vector<uint8_t> first_len;  // [4096]: length of the first codeword of a 12-bit window
-  std::vector<uint8_t> multi;      // [4096]: (whole codewords in the window << 4) | bits they take
+  std::vector<uint16_t> bmask;     // [4096]: bit j set = a codeword of the window ends after j+1 bits
   double avg_bits = 0;
 };
 
@@ -82,7 +82,7 @@ inline SymbolCode build_symbol_code(const std::vector<uint64_t> &freq, int fixed
     c.cw.clear();
     c.len.clear();
     c.first_len.clear();
-    c.multi.clear();
+    c.bmask.clear();
     c.avg_bits = fixed_bits;
     return c;
   };
@@ -128,16 +128,17 @@ inline SymbolCode build_symbol_code(const std::vector<uint64_t> &freq, int fixed
   for (uint8_t v : c.first_len) {
     if (v == 0) return fixed();  // not a complete code (cannot happen for a full binary tree)
   }
-  c.multi.assign(1 << kMaxCodeLen, 0);
+  c.bmask.assign(1 << kMaxCodeLen, 0);
   for (uint32_t w = 0; w < (1u << kMaxCodeLen); w++) {
-    int pos = 0, cnt = 0;
+    int pos = 0;
+    uint32_t bm = 0;
     while (pos < kMaxCodeLen) {
       const int l = c.first_len[(w << pos) & ((1u << kMaxCodeLen) - 1)];
       if (pos + l > kMaxCodeLen) break;
       pos += l;
-      cnt++;
+      bm |= 1u << (pos - 1);
     }
-    c.multi[w] = static_cast<uint8_t>((cnt << 4) | pos);
+    c.bmask[w] = static_cast<uint16_t>(bm);
   }
   double bits = 0;
   for (int i = 0; i < n; i++) bits += static_cast<double>(freq[i]) * L[i];

@@ -33,11 +33,11 @@ __device__ __forceinline__ void load_bytes20(const uint8_t *__restrict__ text, s
   }
 }
 
-// pass 1: number of valid code points per tile, and the number of input bytes they consume
-// (consumed != nbytes  <=>  the reference would print its invalid-unicode warning, utf8.cpp:143-145)
+// pass 1: number of valid code points per tile, and the number of input bytes no code point consumes
+// (dropped != 0  <=>  the reference would print its invalid-unicode warning, utf8.cpp:143-145)
 __global__ __launch_bounds__(kBlock) void decode_count_kernel(const uint8_t *__restrict__ text, size_t nbytes,
                                                               uint32_t *__restrict__ tile_counts,
-                                                              unsigned long long *__restrict__ consumed,
+                                                              unsigned long long *__restrict__ dropped,
                                                               uint32_t *__restrict__ used) {
   __shared__ uint32_t sm[8];
   __shared__ uint32_t low_used[8];  // bitmap of code points < 256 seen by this tile
@@ -93,7 +93,13 @@ __global__ __launch_bounds__(kBlock) void decode_count_kernel(const uint8_t *__r
   (void)block_excl_sum(used_bytes, sm, tot_bytes);
   if (threadIdx.x == 0) {
     tile_counts[blockIdx.x] = tot;
-    atomicAdd(consumed, static_cast<unsigned long long>(tot_bytes));
+    // bytes of this tile that no code point consumed; clean input never touches the counter (one
+    // same-address atomic per tile costs more than the whole pass)
+    const size_t t0 = static_cast<size_t>(blockIdx.x) * kDecTile;
+    const uint32_t tile_bytes = static_cast<uint32_t>(min(static_cast<size_t>(kDecTile), nbytes - t0));
+    if (tot_bytes != tile_bytes) {
+      atomicAdd(dropped, static_cast<unsigned long long>(tile_bytes) - static_cast<unsigned long long>(tot_bytes));
+    }
   }
   if ((low_used[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1u) used[threadIdx.x] = 1u;
 }
@@ -108,7 +114,29 @@ __global__ __launch_bounds__(kBlock) void decode_write_kernel(
   __shared__ uint32_t sm[8];
   __shared__ uint32_t scp[kDecTile];
   __shared__ uint32_t shist[256];
+  __shared__ uint16_t s_ascii[128];  // (class byte << 8) | dense symbol of the ASCII code points
+  // The symbol histogram only steers the code lengths (any histogram gives a valid code), so it is
+  // taken from every 16th tile of large inputs: the per-tile flush is ~50 same-address atomics.
+  const bool sampled = sizeof(SymT) == 1 && (gridDim.x < 256 || (blockIdx.x & 15) == 0);
   if (sizeof(SymT) == 1) shist[threadIdx.x] = 0;
+  auto class_of = [&](uint32_t c) {
+    uint8_t f = 0;
+    if (is_space(c)) f |= kClsSpace;
+    if (is_spacing_char(c)) {
+      f |= kClsSpacing;
+      int lo = 0, hi = nsoft;  // sorted list of "soft" spacing chars (usually empty)
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (soft[mid] < c) lo = mid + 1; else hi = mid;
+      }
+      if (lo < nsoft && soft[lo] == c) f |= kClsSoft;
+    }
+    return f;
+  };
+  if (threadIdx.x < 128) {
+    const uint32_t c = threadIdx.x;
+    s_ascii[c] = static_cast<uint16_t>((static_cast<uint32_t>(class_of(c)) << 8) | ((lut_excl[c] + 1u) & 0xffu));
+  }
   const size_t off = static_cast<size_t>(blockIdx.x) * kDecTile + static_cast<size_t>(threadIdx.x) * kDecBytes;
   uint32_t cp[kDecBytes];
   uint32_t cnt = 0;
@@ -146,24 +174,22 @@ __global__ __launch_bounds__(kBlock) void decode_write_kernel(
   const size_t out_base = tile_prefix[blockIdx.x];
   for (uint32_t k = threadIdx.x; k < tot; k += kBlock) {
     const uint32_t c = scp[k];
-    const uint32_t sv = lut_excl[c] + 1u;
-    sym[out_base + k] = static_cast<SymT>(sv);
-    if (sizeof(SymT) == 1) atomicAdd(&shist[sv & 255u], 1u);
-    if (cps_dbg) cps_dbg[out_base + k] = c;
-    uint8_t f = 0;
-    if (is_space(c)) f |= kClsSpace;
-    if (is_spacing_char(c)) {
-      f |= kClsSpacing;
-      int lo = 0, hi = nsoft;  // sorted list of "soft" spacing chars (usually empty)
-      while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (soft[mid] < c) lo = mid + 1; else hi = mid;
-      }
-      if (lo < nsoft && soft[lo] == c) f |= kClsSoft;
+    uint32_t sv;
+    uint8_t f;
+    if (c < 128 && sizeof(SymT) == 1) {
+      const uint32_t e = s_ascii[c];
+      sv = e & 0xffu;
+      f = static_cast<uint8_t>(e >> 8);
+    } else {
+      sv = lut_excl[c] + 1u;
+      f = class_of(c);
     }
+    sym[out_base + k] = static_cast<SymT>(sv);
+    if (sampled) atomicAdd(&shist[sv & 255u], 1u);
+    if (cps_dbg) cps_dbg[out_base + k] = c;
     cls[out_base + k] = f;
   }
-  if (sizeof(SymT) == 1) {
+  if (sampled) {
     __syncthreads();
     if (shist[threadIdx.x]) atomicAdd(&sym_hist[threadIdx.x], shist[threadIdx.x]);
   }
@@ -195,32 +221,26 @@ __global__ __launch_bounds__(kBlock) void map_vocab_symbols_kernel(const uint32_
 struct DevCode {
   const uint16_t *cw;
   const uint8_t *len;
-  const uint8_t *first_len;  // [4096] then multi[4096] right behind it
+  const uint8_t *first_len;  // the kDecodeTableBytes of count_key_symbols' table (bmask u16[4096])
   int uniform_bits;
 };
 constexpr int kDecodeTableBytes = 2 * 4096;
 
-// number of complete codewords inside the first t bits of a kKeyBits-bit key (t <= kKeyBits).  tab = first_len
-// [4096] followed by multi[4096]: whole 12-bit windows first, single codewords for the rest.
+// number of complete codewords inside the first t bits of a kKeyBits-bit key (t <= kKeyBits).
+// tab = bmask u16[4096] (code.h): the codeword ends inside a 12-bit window as a bit mask, so one
+// table step counts and skips all whole codewords of the window that still fit.
 __device__ __forceinline__ int count_key_symbols(uint64_t key, int t, const uint8_t *tab, int uniform_bits) {
   if (uniform_bits) return t / uniform_bits;
+  const uint16_t *bmask = reinterpret_cast<const uint16_t *>(tab);
   int pos = 0, cnt = 0;
-  while (true) {
+  while (pos < t) {
     const int sh = kKeyBits - pos - 12;
     const uint32_t w = static_cast<uint32_t>(sh >= 0 ? (key >> sh) : (key << -sh)) & 0xfffu;
-    const uint32_t m = tab[4096 + w];
-    const int nb = m & 15;
-    if (nb == 0 || pos + nb > t) break;
-    pos += nb;
-    cnt += m >> 4;
-  }
-  while (true) {
-    const int sh = kKeyBits - pos - 12;
-    const uint32_t w = static_cast<uint32_t>(sh >= 0 ? (key >> sh) : (key << -sh)) & 0xfffu;
-    const int l = tab[w];
-    if (pos + l > t) break;
-    pos += l;
-    cnt++;
+    const int r = t - pos;
+    const uint32_t bm = bmask[w] & (r >= 12 ? 0xfffu : ((1u << r) - 1u));
+    if (!bm) break;
+    cnt += __popc(bm);
+    pos += 32 - __clz(static_cast<int>(bm));
   }
   return cnt;
 }
@@ -228,40 +248,63 @@ __device__ __forceinline__ int count_key_symbols(uint64_t key, int t, const uint
 // Round-0 keys: the first 63 bits of the codeword stream of every suffix (most significant bit
 // first).  Positions past the end read symbol 0, whose codeword is the smallest, so a shorter
 // suffix sorts first.
+//
+// stream(i) = codeword(i) ++ stream(i+1), hence key(i) = cw_i << (63 - l_i) | key(i+1) >> l_i: a lane
+// owns 8 consecutive positions, builds the key of its last one symbol by symbol (≈14 table steps)
+// and rolls the other 7 out of it (one step each).  LDS arrays are indexed p + (p >> 3) so that lanes
+// striding by 8 hit distinct banks; keys leave through LDS as full coalesced rows.
 constexpr int kKeyItems = 8;
 constexpr int kKeyTile = kBlock * kKeyItems;
 constexpr int kKeyHalo = 64;
+__device__ __forceinline__ int key_pad(int p) { return p + (p >> 3); }
 template <typename SymT>
 __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restrict__ sym, size_t n, DevCode code,
                                                              uint64_t *__restrict__ keys,
                                                              uint32_t *__restrict__ vals) {
-  __shared__ uint32_t ss[kKeyTile + kKeyHalo];
+  constexpr int kSymSlots = kKeyTile + kKeyHalo;
+  __shared__ uint32_t ss[kSymSlots + kSymSlots / 8 + 1];
   __shared__ uint32_t stab[256];  // (len << 16) | codeword
+  __shared__ uint64_t skey[kKeyTile + kKeyTile / 8 + 1];
   const size_t base = static_cast<size_t>(blockIdx.x) * kKeyTile;
-  for (int k = threadIdx.x; k < kKeyTile + kKeyHalo; k += kBlock) {
+  for (int k = threadIdx.x; k < kSymSlots; k += kBlock) {
     size_t i = base + k;
-    ss[k] = i < n ? static_cast<uint32_t>(sym[i]) : 0u;
+    ss[key_pad(k)] = i < n ? static_cast<uint32_t>(sym[i]) : 0u;
   }
   const int ub = code.uniform_bits;
   if (!ub) stab[threadIdx.x] = (static_cast<uint32_t>(code.len[threadIdx.x]) << 16) | code.cw[threadIdx.x];
+  __syncthreads();
+  const int p0 = threadIdx.x * kKeyItems;
+  if (base + p0 < n) {
+    uint64_t key = 0;
+    int used = 0, q = p0 + kKeyItems - 1;
+    while (used < kKeyBits) {  // key of the lane's last position
+      const uint32_t sv = ss[key_pad(q)];
+      q++;
+      const uint32_t e = ub ? 0u : stab[sv];
+      const int l = ub ? ub : static_cast<int>(e >> 16);
+      const uint32_t c = ub ? sv : (e & 0xffffu);
+      const int take = min(l, kKeyBits - used);
+      key = (key << take) | (c >> (l - take));
+      used += take;
+    }
+    skey[key_pad(p0 + kKeyItems - 1)] = key;
+#pragma unroll
+    for (int j = kKeyItems - 2; j >= 0; j--) {
+      const uint32_t sv = ss[key_pad(p0 + j)];
+      const uint32_t e = ub ? 0u : stab[sv];
+      const int l = ub ? ub : static_cast<int>(e >> 16);
+      const uint64_t c = ub ? sv : (e & 0xffffu);
+      key = (c << (kKeyBits - l)) | (key >> l);
+      skey[key_pad(p0 + j)] = key;
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < kKeyItems; j++) {
     const int li = j * kBlock + threadIdx.x;
     const size_t i = base + li;
     if (i < n) {
-      uint64_t key = 0;
-      int used = 0, q = li;
-      while (used < kKeyBits) {
-        const uint32_t sv = ss[q++];
-        const uint32_t e = ub ? 0u : stab[sv];
-        const int l = ub ? ub : static_cast<int>(e >> 16);
-        const uint32_t c = ub ? sv : (e & 0xffffu);
-        const int take = min(l, kKeyBits - used);
-        key = (key << take) | (c >> (l - take));
-        used += take;
-      }
-      keys[i] = key;
+      keys[i] = skey[key_pad(li)];
       vals[i] = static_cast<uint32_t>(i);
     }
   }

@@ -88,7 +88,7 @@ struct Context {
   DeviceBuffer text_buf, a_buf, b_buf;
   uint32_t *d_used = nullptr, *d_lut = nullptr, *d_scan_tmp = nullptr;  // code point tables
   uint32_t *d_scalars = nullptr;                                         // 16 words of device scalars
-  uint8_t *d_code = nullptr;     // symbol code tables: cw u16[256] | len u8[256] | first_len u8[4096]
+  uint8_t *d_code = nullptr;     // symbol code tables: cw u16[256] | len u8[256] | bmask u16[4096]
   uint32_t *d_symhist = nullptr;  // 256 counters
   uint32_t *h_scalars = nullptr;                                         // pinned mirror
   RadixStats rstats;
@@ -250,9 +250,9 @@ static void encode_on_device(wp_vocab *v, const uint8_t *d_text, size_t nbytes, 
   fetch_scalars(c, 4);
   const size_t n_text = c->h_scalars[0];
   const uint32_t sigma = c->h_scalars[1];
-  unsigned long long consumed;
-  std::memcpy(&consumed, c->h_scalars + 2, sizeof(consumed));
-  if (consumed != nbytes) std::cerr << "WARNING Input contains invalid unicode characters." << std::endl;
+  unsigned long long dropped;
+  std::memcpy(&dropped, c->h_scalars + 2, sizeof(dropped));
+  if (dropped != 0) std::cerr << "WARNING Input contains invalid unicode characters." << std::endl;
 
   const size_t n = n_text + 1 + hv.stream.size();  // total_length, linear.cpp:77-82
   S.n_text = static_cast<int64_t>(n_text);
@@ -406,8 +406,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     std::vector<uint8_t> blob(512 + 256 + kDecodeTableBytes, 0);
     std::memcpy(blob.data(), code.cw.data(), code.cw.size() * sizeof(uint16_t));
     std::memcpy(blob.data() + 512, code.len.data(), code.len.size());
-    std::memcpy(blob.data() + 768, code.first_len.data(), 4096);
-    std::memcpy(blob.data() + 768 + 4096, code.multi.data(), 4096);
+    std::memcpy(blob.data() + 768, code.bmask.data(), kDecodeTableBytes);
     WP_HIP(hipMemcpyAsync(c->d_code, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
     WP_HIP(hipStreamSynchronize(st));  // blob is a stack object
   }
