@@ -223,7 +223,10 @@ __global__ __launch_bounds__(kBlock) void scatter_pairs_kernel(const uint32_t *_
 
 // Pass 2: applies one round's split.  ROUND0: list == all slots (slot k == k), keys are the packed
 // codeword streams.  Later rounds: keys = (group id << 32 | second key), adep = depth of the
-// entry's (old) group.
+// entry's (old) group.  Everything the second half needs from the keys (the key itself, the common
+// bit prefix with the previous key, "same old group as the previous entry") is taken in the first
+// half and kept in registers / ballots: with ~190 tiles in flight per XCD the 16 KB of keys of a tile
+// do not survive in the 4 MB L2 until the tile prefix is known, and a second read came from HBM.
 template <typename SymT, bool ROUND0>
 __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ slots,
@@ -243,24 +246,44 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
   }
   const int lane = lane_id(), w = wave_id();
   const size_t wave_base = static_cast<size_t>(blockIdx.x) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
-  const RerankAgg pre = tile_prefix_agg(agg, chunk_agg, blockIdx.x, s_red);
   const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
 
-  uint64_t bfs[kRrRounds], bas[kRrRounds], bhs[kRrRounds];
+  uint64_t bfs[kRrRounds], bas[kRrRounds], bss[kRrRounds], bos[kRrRounds];
+  uint64_t mes[kRrRounds];
+  uint32_t nds[kRrRounds];
   uint32_t na = 0, nh = 0, last = 0;
 #pragma unroll
   for (int r = 0; r < kRrRounds; r++) {
     const size_t k = wave_base + static_cast<size_t>(r) * kWave + lane;
-    bool f = false, sg = true, act = false;
+    bool f = false, sg = false, act = false, same_old = false;
+    uint64_t me = 0;
+    uint32_t nd = 0;
     if (k < m) {
-      rr_flags(keys, m, k, f, sg);
-      if (!sg) act = rule.full || tdep[k] < rule.need;
+      me = keys[k];
+      const uint64_t prev = k > 0 ? keys[k - 1] : ~me;
+      const uint64_t next = k + 1 < m ? keys[k + 1] : ~me;
+      f = prev != me;
+      sg = f && next != me;
+      if (!sg) {
+        nd = tdep[k];
+        act = rule.full || nd < rule.need;
+      }
+      if (ROUND0) {
+        // for a group head: bits of the key shared with the previous key (lcp below)
+        nd = f ? ((k > 0 ? static_cast<uint32_t>(__clzll(static_cast<long long>(me ^ prev))) : 0u) << 16) | min(nd, 0xffffu)
+               : min(nd, 0xffffu);
+      } else {
+        same_old = k > 0 && (me >> 32) == (prev >> 32);
+      }
     }
+    mes[r] = me;
+    nds[r] = nd;
     bfs[r] = __ballot(f);
     bas[r] = __ballot(act);
-    bhs[r] = __ballot(f && act);
+    bss[r] = __ballot(sg);
+    bos[r] = __ballot(same_old);
     na += __popcll(bas[r]);
-    nh += __popcll(bhs[r]);
+    nh += __popcll(bfs[r] & bas[r]);
     if (bfs[r]) last = static_cast<uint32_t>(wave_base + static_cast<size_t>(r) * kWave + (63 - __clzll(static_cast<long long>(bfs[r]))) + 1);
   }
   if (lane == 0) {
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     s_nh[w] = nh;
     s_last[w] = last;
   }
-  __syncthreads();
+  const RerankAgg pre = tile_prefix_agg(agg, chunk_agg, blockIdx.x, s_red);  // (has the barriers for s_na.. too)
   if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {  // the last tile knows the totals of the round
     const uint32_t ta = pre.n_active + s_na[0] + s_na[1] + s_na[2] + s_na[3];
     const uint32_t th = pre.n_heads + s_nh[0] + s_nh[1] + s_nh[2] + s_nh[3];
@@ -282,41 +305,44 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     eh += s_nh[i];
     head1 = max(head1, s_last[i]);
   }
+  // rounds >= 1: does the group of the carried head continue the old group of the entry before it?
+  // (then it is not the first subgroup of its old group and its rank changes)
+  bool chg1 = true;
+  if (!ROUND0) {
+    chg1 = false;
+    if (head1 > 1) chg1 = (keys[head1 - 1] >> 32) == (keys[head1 - 2] >> 32);
+  }
 
 #pragma unroll
   for (int r = 0; r < kRrRounds; r++) {
     const size_t round_base = wave_base + static_cast<size_t>(r) * kWave;
     const size_t k = round_base + lane;
-    const uint64_t bf = bfs[r], ba = bas[r], bh = bhs[r];
+    const uint64_t bf = bfs[r], ba = bas[r], bh = bfs[r] & bas[r];
     if (k < m) {
       const uint64_t mine = bf & le;
-      const size_t head = mine ? round_base + (63 - __clzll(static_cast<long long>(mine)))
-                               : (head1 ? static_cast<size_t>(head1) - 1 : 0);
+      const int hl = 63 - __clzll(static_cast<long long>(mine));  // lane of my head, if it is in this round
+      const size_t head = mine ? round_base + hl : (head1 ? static_cast<size_t>(head1) - 1 : 0);
       const bool f = (bf >> lane) & 1ull;
       const bool act = (ba >> lane) & 1ull;
+      const bool single = (bss[r] >> lane) & 1ull;
       const uint32_t v = vals[k];
       const uint32_t x = ROUND0 ? static_cast<uint32_t>(k) : slots[k];
       const uint32_t head_slot = ROUND0 ? static_cast<uint32_t>(head) : slots[head];
-      const uint64_t me = keys[k];
-      const bool single = f && (k + 1 == m || keys[k + 1] != me);
       if (sa) sa[x] = v;  // the suffix array itself is only kept for debug fetches / the Kasai kernel
       // new rank entry of suffix v, scattered to the rank table afterwards.  In rounds >= 1 the
       // first subgroup of an old group keeps its rank (its head is the old head): left unchanged.
       bool changed = true;
-      if (!ROUND0) changed = head > 0 && (keys[head] >> 32) == (keys[head - 1] >> 32);
-      const uint32_t nd = single ? 0u : tdep[k];
+      if (!ROUND0) changed = mine ? ((bos[r] >> hl) & 1ull) != 0 : chg1;
+      const uint32_t nd = single ? 0u : (ROUND0 ? (nds[r] & 0xffffu) : nds[r]);
       hd[k] = changed ? head_slot : kRankUnchanged;
       if (f && !single) gdepth[x] = nd;  // x is the first slot of this (still tied) group
       if (ROUND0) {
         if (k > 0) {
           int32_t l = -1;
-          if (f) {
-            const uint64_t d = me ^ keys[k - 1];
-            l = count_key_symbols(me, __clzll(static_cast<long long>(d)) - (64 - kKeyBits), s_fl, uniform_bits);
-          }
+          if (f) l = count_key_symbols(mes[r], static_cast<int>(nds[r] >> 16) - (64 - kKeyBits), s_fl, uniform_bits);
           lcp[x - 1] = l;
         }
-      } else if (f && k > 0 && (me >> 32) == (keys[k - 1] >> 32)) {
+      } else if (f && ((bos[r] >> lane) & 1ull)) {
         // a new boundary inside an old group (x-1 is the previous list entry's slot): the two
         // suffixes share the old group's depth and then differ within the second keys' reach
         const uint32_t d = adep[k];
@@ -336,7 +362,11 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     }
     ea += __popcll(ba);
     eh += __popcll(bh);
-    if (bf) head1 = static_cast<uint32_t>(round_base + (63 - __clzll(static_cast<long long>(bf))) + 1);
+    if (bf) {
+      const int hl = 63 - __clzll(static_cast<long long>(bf));
+      head1 = static_cast<uint32_t>(round_base + hl + 1);
+      if (!ROUND0) chg1 = (bos[r] >> hl) & 1ull;
+    }
   }
 }
 
