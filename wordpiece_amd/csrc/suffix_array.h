@@ -221,37 +221,30 @@ __global__ __launch_bounds__(kBlock) void scatter_pairs_kernel(const uint32_t *_
   }
 }
 
-// Pass 2: applies one round's split.  ROUND0: list == all slots (slot k == k), keys are the packed
-// codeword streams.  Later rounds: keys = (group id << 32 | second key), adep = depth of the
-// entry's (old) group.  Everything the second half needs from the keys (the key itself, the common
-// bit prefix with the previous key, "same old group as the previous entry") is taken in the first
-// half and kept in registers / ballots: with ~190 tiles in flight per XCD the 16 KB of keys of a tile
-// do not survive in the 4 MB L2 until the tile prefix is known, and a second read came from HBM.
-template <typename SymT, bool ROUND0>
-__global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
-    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ slots,
-    const uint32_t *__restrict__ adep, const uint32_t *__restrict__ tdep, size_t m,
-    const RerankAgg *__restrict__ agg, const RerankAgg *__restrict__ chunk_agg, const SymT *__restrict__ sym, size_t n,
-    const uint8_t *__restrict__ first_len, int uniform_bits, DepthRule rule, uint32_t *__restrict__ sa,
-    RankEntry *__restrict__ hd, int32_t *__restrict__ lcp, uint32_t *__restrict__ nslots,
-    uint32_t *__restrict__ nvals, uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep,
-    uint32_t *__restrict__ ghead, uint32_t *__restrict__ gdepth, uint32_t *__restrict__ totals) {
-  __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
-  __shared__ uint32_t s_red[3][4];
-  __shared__ uint8_t s_fl[kDecodeTableBytes];
-  if (ROUND0 && !uniform_bits) {
-    for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
-      reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
-    }
-  }
-  const int lane = lane_id(), w = wave_id();
-  const size_t wave_base = static_cast<size_t>(blockIdx.x) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
-  const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+// ---- the split of one round ------------------------------------------------------------------------
+// ROUND0: list == all slots (slot k == k), keys are the packed codeword streams.  Later rounds:
+// keys = (group id << 32 | second key), adep = depth of the entry's (old) group.
+// A workgroup handles its tile in two halves with the tile prefix in between.  Everything the second
+// half needs from the keys (the key itself, the common bit prefix with the previous key, "same old
+// group as the previous entry") is taken in the first half and kept in registers / ballots: with
+// ~190 tiles in flight per XCD the 16 KB of keys of a tile do not survive in the 4 MB L2 until the
+// tile prefix is known, and a second read came from HBM.
+struct RrTile {
+  uint64_t bfs[kRrRounds], bas[kRrRounds], bss[kRrRounds], bos[kRrRounds];  // head / active / single / same old group
+  uint64_t mes[kRrRounds];                                                   // the entry's key
+  uint32_t nds[kRrRounds];  // new depth; ROUND0: | bits shared with the previous key << 16 (for heads)
+  uint32_t na, nh, last;    // wave totals: active, active heads, 1 + last head
+};
 
-  uint64_t bfs[kRrRounds], bas[kRrRounds], bss[kRrRounds], bos[kRrRounds];
-  uint64_t mes[kRrRounds];
-  uint32_t nds[kRrRounds];
-  uint32_t na = 0, nh = 0, last = 0;
+// OWN_DEPTH: the new depth is computed here (single-pass kernel) instead of read from tdep
+template <bool ROUND0, bool OWN_DEPTH>
+__device__ __forceinline__ void rr_first_half(RrTile &T, const uint64_t *__restrict__ keys, size_t m, size_t wave_base,
+                                              const uint32_t *__restrict__ tdep, const uint32_t *__restrict__ vals,
+                                              const uint32_t *__restrict__ adep, const RankEntry *__restrict__ rd,
+                                              const uint32_t *__restrict__ gdepth_in, size_t n, const uint8_t *s_fl,
+                                              int uniform_bits, DepthRule rule) {
+  const int lane = lane_id();
+  T.na = T.nh = T.last = 0;
 #pragma unroll
   for (int r = 0; r < kRrRounds; r++) {
     const size_t k = wave_base + static_cast<size_t>(r) * kWave + lane;
@@ -265,46 +258,55 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
       f = prev != me;
       sg = f && next != me;
       if (!sg) {
-        nd = tdep[k];
+        if (!OWN_DEPTH) {
+          nd = tdep[k];
+        } else if (ROUND0) {
+          nd = static_cast<uint32_t>(count_key_symbols(me, kKeyBits, s_fl, uniform_bits));
+        } else {
+          const uint32_t d = adep[k];
+          const size_t t = static_cast<size_t>(vals[k]) + d;
+          const uint32_t dj = t < n ? gdepth_in[rd[t]] : 0u;
+          nd = min(d + dj, 0x7fffffffu);
+        }
         act = rule.full || nd < rule.need;
       }
       if (ROUND0) {
-        // for a group head: bits of the key shared with the previous key (lcp below)
-        nd = f ? ((k > 0 ? static_cast<uint32_t>(__clzll(static_cast<long long>(me ^ prev))) : 0u) << 16) | min(nd, 0xffffu)
-               : min(nd, 0xffffu);
+        nd = min(nd, 0xffffu);
+        if (f && k > 0) nd |= static_cast<uint32_t>(__clzll(static_cast<long long>(me ^ prev))) << 16;
       } else {
         same_old = k > 0 && (me >> 32) == (prev >> 32);
       }
     }
-    mes[r] = me;
-    nds[r] = nd;
-    bfs[r] = __ballot(f);
-    bas[r] = __ballot(act);
-    bss[r] = __ballot(sg);
-    bos[r] = __ballot(same_old);
-    na += __popcll(bas[r]);
-    nh += __popcll(bfs[r] & bas[r]);
-    if (bfs[r]) last = static_cast<uint32_t>(wave_base + static_cast<size_t>(r) * kWave + (63 - __clzll(static_cast<long long>(bfs[r]))) + 1);
+    T.mes[r] = me;
+    T.nds[r] = nd;
+    T.bfs[r] = __ballot(f);
+    T.bas[r] = __ballot(act);
+    T.bss[r] = __ballot(sg);
+    T.bos[r] = __ballot(same_old);
+    T.na += __popcll(T.bas[r]);
+    T.nh += __popcll(T.bfs[r] & T.bas[r]);
+    if (T.bfs[r]) {
+      T.last = static_cast<uint32_t>(wave_base + static_cast<size_t>(r) * kWave + (63 - __clzll(static_cast<long long>(T.bfs[r]))) + 1);
+    }
   }
-  if (lane == 0) {
-    s_na[w] = na;
-    s_nh[w] = nh;
-    s_last[w] = last;
-  }
-  const RerankAgg pre = tile_prefix_agg(agg, chunk_agg, blockIdx.x, s_red);  // (has the barriers for s_na.. too)
-  if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {  // the last tile knows the totals of the round
-    const uint32_t ta = pre.n_active + s_na[0] + s_na[1] + s_na[2] + s_na[3];
-    const uint32_t th = pre.n_heads + s_nh[0] + s_nh[1] + s_nh[2] + s_nh[3];
-    totals[0] = ta;
-    totals[1] = th;
-    ghead[th] = ta;  // sentinel: group g of the next list is [ghead[g], ghead[g+1])
-  }
-  uint32_t ea = pre.n_active, eh = pre.n_heads, head1 = pre.last_flag;  // head1: 1-based list index
-  for (int i = 0; i < w; i++) {
-    ea += s_na[i];
-    eh += s_nh[i];
-    head1 = max(head1, s_last[i]);
-  }
+}
+
+// ea / eh / head1: entries that stay active, their heads, 1 + last head — all before this wave.
+// gd != nullptr: park the new group depths in gd[] instead of storing them to gdepth (single-pass
+// kernel, rounds >= 1, see there).
+template <typename SymT, bool ROUND0>
+__device__ __forceinline__ void rr_second_half(const RrTile &T, const uint64_t *__restrict__ keys, size_t m,
+                                               size_t wave_base, uint32_t ea, uint32_t eh, uint32_t head1,
+                                               const uint32_t *__restrict__ vals, const uint32_t *__restrict__ slots,
+                                               const uint32_t *__restrict__ adep, const SymT *__restrict__ sym, size_t n,
+                                               const uint8_t *s_fl, int uniform_bits, uint32_t *__restrict__ sa,
+                                               RankEntry *__restrict__ hd, int32_t *__restrict__ lcp,
+                                               uint32_t *__restrict__ nslots, uint32_t *__restrict__ nvals,
+                                               uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep,
+                                               uint32_t *__restrict__ ghead, uint32_t *__restrict__ gdepth,
+                                               uint32_t *__restrict__ gd) {
+  const int lane = lane_id();
+  const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
   // rounds >= 1: does the group of the carried head continue the old group of the entry before it?
   // (then it is not the first subgroup of its old group and its rank changes)
   bool chg1 = true;
@@ -312,19 +314,18 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     chg1 = false;
     if (head1 > 1) chg1 = (keys[head1 - 1] >> 32) == (keys[head1 - 2] >> 32);
   }
-
 #pragma unroll
   for (int r = 0; r < kRrRounds; r++) {
     const size_t round_base = wave_base + static_cast<size_t>(r) * kWave;
     const size_t k = round_base + lane;
-    const uint64_t bf = bfs[r], ba = bas[r], bh = bfs[r] & bas[r];
+    const uint64_t bf = T.bfs[r], ba = T.bas[r], bh = T.bfs[r] & T.bas[r];
     if (k < m) {
       const uint64_t mine = bf & le;
       const int hl = 63 - __clzll(static_cast<long long>(mine));  // lane of my head, if it is in this round
       const size_t head = mine ? round_base + hl : (head1 ? static_cast<size_t>(head1) - 1 : 0);
       const bool f = (bf >> lane) & 1ull;
       const bool act = (ba >> lane) & 1ull;
-      const bool single = (bss[r] >> lane) & 1ull;
+      const bool single = (T.bss[r] >> lane) & 1ull;
       const uint32_t v = vals[k];
       const uint32_t x = ROUND0 ? static_cast<uint32_t>(k) : slots[k];
       const uint32_t head_slot = ROUND0 ? static_cast<uint32_t>(head) : slots[head];
@@ -332,17 +333,21 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
       // new rank entry of suffix v, scattered to the rank table afterwards.  In rounds >= 1 the
       // first subgroup of an old group keeps its rank (its head is the old head): left unchanged.
       bool changed = true;
-      if (!ROUND0) changed = mine ? ((bos[r] >> hl) & 1ull) != 0 : chg1;
-      const uint32_t nd = single ? 0u : (ROUND0 ? (nds[r] & 0xffffu) : nds[r]);
+      if (!ROUND0) changed = mine ? ((T.bos[r] >> hl) & 1ull) != 0 : chg1;
+      const uint32_t nd = single ? 0u : (ROUND0 ? (T.nds[r] & 0xffffu) : T.nds[r]);
       hd[k] = changed ? head_slot : kRankUnchanged;
-      if (f && !single) gdepth[x] = nd;  // x is the first slot of this (still tied) group
+      if (gd) {
+        gd[k] = (f && !single) ? nd : kRankUnchanged;
+      } else if (f && !single) {
+        gdepth[x] = nd;  // x is the first slot of this (still tied) group
+      }
       if (ROUND0) {
         if (k > 0) {
           int32_t l = -1;
-          if (f) l = count_key_symbols(mes[r], static_cast<int>(nds[r] >> 16) - (64 - kKeyBits), s_fl, uniform_bits);
+          if (f) l = count_key_symbols(T.mes[r], static_cast<int>(T.nds[r] >> 16) - (64 - kKeyBits), s_fl, uniform_bits);
           lcp[x - 1] = l;
         }
-      } else if (f && ((bos[r] >> lane) & 1ull)) {
+      } else if (f && ((T.bos[r] >> lane) & 1ull)) {
         // a new boundary inside an old group (x-1 is the previous list entry's slot): the two
         // suffixes share the old group's depth and then differ within the second keys' reach
         const uint32_t d = adep[k];
@@ -365,20 +370,68 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     if (bf) {
       const int hl = 63 - __clzll(static_cast<long long>(bf));
       head1 = static_cast<uint32_t>(round_base + hl + 1);
-      if (!ROUND0) chg1 = (bos[r] >> hl) & 1ull;
+      if (!ROUND0) chg1 = (T.bos[r] >> hl) & 1ull;
     }
   }
 }
 
-// ---- single-pass rerank: the two passes above fused with a chained scan --------------------------
+// Pass 2 of the three-kernel form: tile prefix from the aggregates of pass 1, then the split.
+template <typename SymT, bool ROUND0>
+__global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ slots,
+    const uint32_t *__restrict__ adep, const uint32_t *__restrict__ tdep, size_t m,
+    const RerankAgg *__restrict__ agg, const RerankAgg *__restrict__ chunk_agg, const SymT *__restrict__ sym, size_t n,
+    const uint8_t *__restrict__ first_len, int uniform_bits, DepthRule rule, uint32_t *__restrict__ sa,
+    RankEntry *__restrict__ hd, int32_t *__restrict__ lcp, uint32_t *__restrict__ nslots,
+    uint32_t *__restrict__ nvals, uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep,
+    uint32_t *__restrict__ ghead, uint32_t *__restrict__ gdepth, uint32_t *__restrict__ totals) {
+  __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
+  __shared__ uint32_t s_red[3][4];
+  __shared__ uint8_t s_fl[kDecodeTableBytes];
+  if (ROUND0 && !uniform_bits) {
+    for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
+      reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
+    }
+  }
+  const int lane = lane_id(), w = wave_id();
+  const size_t wave_base = static_cast<size_t>(blockIdx.x) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
+  RrTile T;
+  rr_first_half<ROUND0, false>(T, keys, m, wave_base, tdep, nullptr, nullptr, nullptr, nullptr, n, s_fl, uniform_bits,
+                               rule);
+  if (lane == 0) {
+    s_na[w] = T.na;
+    s_nh[w] = T.nh;
+    s_last[w] = T.last;
+  }
+  const RerankAgg pre = tile_prefix_agg(agg, chunk_agg, blockIdx.x, s_red);  // (has the barriers for s_na.. too)
+  if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {  // the last tile knows the totals of the round
+    const uint32_t ta = pre.n_active + s_na[0] + s_na[1] + s_na[2] + s_na[3];
+    const uint32_t th = pre.n_heads + s_nh[0] + s_nh[1] + s_nh[2] + s_nh[3];
+    totals[0] = ta;
+    totals[1] = th;
+    ghead[th] = ta;  // sentinel: group g of the next list is [ghead[g], ghead[g+1])
+  }
+  uint32_t ea = pre.n_active, eh = pre.n_heads, head1 = pre.last_flag;  // head1: 1-based list index
+  for (int i = 0; i < w; i++) {
+    ea += s_na[i];
+    eh += s_nh[i];
+    head1 = max(head1, s_last[i]);
+  }
+  rr_second_half<SymT, ROUND0>(T, keys, m, wave_base, ea, eh, head1, vals, slots, adep, sym, n, s_fl, uniform_bits, sa,
+                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, nullptr);
+}
+
+// ---- single-pass form: the two passes fused with a chained scan ----------------------------------
 // The split of a round needs, per tile of the list, the exclusive prefix of three scalars (entries
 // that stay active, their group heads, position of the last group head).  Here every workgroup takes
 // a tile ticket (so all lower tiles are running or done), publishes its three scalars as an
 // AGGREGATE, looks back over its predecessors 64 tiles per step (one wave, one predecessor per
 // lane) until it meets an INCLUSIVE prefix, publishes its own INCLUSIVE prefix and carries on with
-// the apply pass — no separate counting pass over the keys, no spine kernel, no tdep round trip.
+// the second half — no separate counting pass over the keys, no tdep round trip.
 // A tile's state is two 64-bit words written/read with relaxed agent-scope atomics (flag and value
 // in one word); a reader only accepts a tile whose two words carry the same flag.
+// Rounds >= 1: tiles still in their first half read the OLD group depths through gdepth_in, so the
+// new depth of a group head is parked in gd[] and stored by gdepth_store_kernel after this launch.
 constexpr uint64_t kLbAgg = 1ull << 62, kLbIncl = 2ull << 62, kLbFlagMask = 3ull << 62;
 
 struct LookbackState {
@@ -410,43 +463,12 @@ __global__ __launch_bounds__(kBlock) void rerank_fused_kernel(
   const unsigned tile = s_tile;
   const int lane = lane_id(), w = wave_id();
   const size_t wave_base = static_cast<size_t>(tile) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
-  const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
-
-  // ---- phase 1: flags, new depths (kept in registers), tile counts
-  uint64_t bfs[kRrRounds], bas[kRrRounds], bhs[kRrRounds];
-  uint32_t nds[kRrRounds];
-  uint32_t na = 0, nh = 0, last = 0;
-#pragma unroll
-  for (int r = 0; r < kRrRounds; r++) {
-    const size_t k = wave_base + static_cast<size_t>(r) * kWave + lane;
-    bool f = false, sg = true, act = false;
-    uint32_t nd = 0;
-    if (k < m) {
-      rr_flags(keys, m, k, f, sg);
-      if (!sg) {
-        if (ROUND0) {
-          nd = static_cast<uint32_t>(count_key_symbols(keys[k], kKeyBits, s_fl, uniform_bits));
-        } else {
-          const uint32_t d = adep[k];
-          const size_t t = static_cast<size_t>(vals[k]) + d;
-          const uint32_t dj = t < n ? gdepth_in[rd[t]] : 0u;
-          nd = min(d + dj, 0x7fffffffu);
-        }
-        act = rule.full || nd < rule.need;
-      }
-    }
-    nds[r] = nd;
-    bfs[r] = __ballot(f);
-    bas[r] = __ballot(act);
-    bhs[r] = __ballot(f && act);
-    na += __popcll(bas[r]);
-    nh += __popcll(bhs[r]);
-    if (bfs[r]) last = static_cast<uint32_t>(wave_base + static_cast<size_t>(r) * kWave + (63 - __clzll(static_cast<long long>(bfs[r]))) + 1);
-  }
+  RrTile T;
+  rr_first_half<ROUND0, true>(T, keys, m, wave_base, nullptr, vals, adep, rd, gdepth_in, n, s_fl, uniform_bits, rule);
   if (lane == 0) {
-    s_na[w] = na;
-    s_nh[w] = nh;
-    s_last[w] = last;
+    s_na[w] = T.na;
+    s_nh[w] = T.nh;
+    s_last[w] = T.last;
   }
   __syncthreads();
 
@@ -518,65 +540,8 @@ __global__ __launch_bounds__(kBlock) void rerank_fused_kernel(
     eh += s_nh[i];
     head1 = max(head1, s_last[i]);
   }
-
-  // ---- phase 2: apply (same as rerank_apply_kernel)
-#pragma unroll
-  for (int r = 0; r < kRrRounds; r++) {
-    const size_t round_base = wave_base + static_cast<size_t>(r) * kWave;
-    const size_t k = round_base + lane;
-    const uint64_t bf = bfs[r], ba = bas[r], bh = bhs[r];
-    if (k < m) {
-      const uint64_t mine = bf & le;
-      const size_t head = mine ? round_base + (63 - __clzll(static_cast<long long>(mine)))
-                               : (head1 ? static_cast<size_t>(head1) - 1 : 0);
-      const bool f = (bf >> lane) & 1ull;
-      const bool act = (ba >> lane) & 1ull;
-      const uint32_t v = vals[k];
-      const uint32_t x = ROUND0 ? static_cast<uint32_t>(k) : slots[k];
-      const uint32_t head_slot = ROUND0 ? static_cast<uint32_t>(head) : slots[head];
-      const uint64_t me = keys[k];
-      const bool single = f && (k + 1 == m || keys[k + 1] != me);
-      if (sa) sa[x] = v;
-      bool changed = true;
-      if (!ROUND0) changed = head > 0 && (keys[head] >> 32) == (keys[head - 1] >> 32);
-      const uint32_t nd = single ? 0u : nds[r];
-      hd[k] = changed ? head_slot : kRankUnchanged;
-      // Rounds >= 1: tiles still in phase 1 read the OLD depths through gdepth_in, so the new depth
-      // of a group head is parked in gd[] and stored by gdepth_store_kernel after this launch.
-      if (ROUND0) {
-        if (f && !single) gdepth[x] = nd;
-      } else {
-        gd[k] = (f && !single) ? nd : kRankUnchanged;
-      }
-      if (ROUND0) {
-        if (k > 0) {
-          int32_t l = -1;
-          if (f) {
-            const uint64_t d = me ^ keys[k - 1];
-            l = count_key_symbols(me, __clzll(static_cast<long long>(d)) - (64 - kKeyBits), s_fl, uniform_bits);
-          }
-          lcp[x - 1] = l;
-        }
-      } else if (f && k > 0 && (me >> 32) == (keys[k - 1] >> 32)) {
-        const uint32_t d = adep[k];
-        lcp[x - 1] = static_cast<int32_t>(d)
-                     + lcp_compare(sym, n, static_cast<size_t>(vals[k - 1]) + d, static_cast<size_t>(v) + d,
-                                   0x7fffffff);
-      }
-      if (act) {
-        const uint32_t pos = ea + __popcll(ba & lt);
-        const uint32_t g = eh + __popcll(bh & le) - 1;
-        nslots[pos] = x;
-        nvals[pos] = v;
-        ngid[pos] = g;
-        ndep[pos] = nd;
-        if (f) ghead[g] = pos;
-      }
-    }
-    ea += __popcll(ba);
-    eh += __popcll(bh);
-    if (bf) head1 = static_cast<uint32_t>(round_base + (63 - __clzll(static_cast<long long>(bf))) + 1);
-  }
+  rr_second_half<SymT, ROUND0>(T, keys, m, wave_base, ea, eh, head1, vals, slots, adep, sym, n, s_fl, uniform_bits, sa,
+                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, ROUND0 ? nullptr : gd);
 }
 
 __global__ __launch_bounds__(kBlock) void gdepth_store_kernel(const uint32_t *__restrict__ gd,
