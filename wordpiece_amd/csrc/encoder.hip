@@ -423,7 +423,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   auto classify_groups = [&](size_t list_len) {
     if (list_len <= static_cast<size_t>(kLsMaxGroup)) return false;  // no group can be large
     const size_t cap = list_len / 2 + 1;  // a group has >= 2 entries
-    hipLaunchKernelGGL(group_classify_kernel, dim3(cdiv(cap, kBlock)), dim3(kBlock), 0, st2, d_ghead,
+    hipLaunchKernelGGL(group_classify_kernel, dim3(std::min<size_t>(cdiv(cap, kBlock), 4096)), dim3(kBlock), 0, st2, d_ghead,
                        c->d_scalars + 5, d_large_id, d_large_off, cap);
     device_exclusive_scan(d_large_id, d_large_id, cap, d_gscan_tmp, c->d_scalars + 6, st2, c->d_scalars + 5);
     device_exclusive_scan(d_large_off, d_large_off, cap, d_gscan_tmp, c->d_scalars + 7, st2, c->d_scalars + 5);
@@ -439,10 +439,10 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       const int hb = bit_length(n - 1);
       const int bc = radix_sort_pairs<uint32_t>(dst, val, t_dst, t_val, m, std::max(0, hb - bin_bits), hb, d_radix_tmp,
                                                 st, nullptr);
-      hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kBlock)), dim3(kBlock), 0, st, bc ? t_dst : dst,
+      hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, bc ? t_dst : dst,
                          bc ? t_val : val, m, d_rank, 1);
     } else {
-      hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kBlock)), dim3(kBlock), 0, st, dst, val, m, d_rank, 0);
+      hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, dst, val, m, d_rank, 0);
     }
   };
   int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, kKeyBits, d_radix_tmp, st, &c->rstats);
@@ -499,7 +499,8 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     classified = classify_groups(n);
     join();
   }
-  fetch_scalars(c, 8);
+  fetch_scalars(c, 11);
+  const size_t n_anchors = n_text > 0 ? c->h_scalars[10] : 0;  // (the side stream was joined above)
   size_t n_act = c->h_scalars[4], n_groups = c->h_scalars[5];
   size_t n_large_groups = classified ? c->h_scalars[6] : 0, n_large = classified ? c->h_scalars[7] : 0;
   int rounds = 1;
@@ -517,7 +518,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                        d_ghead, static_cast<uint32_t>(n_groups), d_rank, n, rb, skeys, svals);
     if (n_large > 0) {  // large groups (side stream, disjoint list positions): extract, global radix sort on
                         // (dense large id, second key), write back
-      hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st2, avals, AG, adep,
+      hipLaunchKernelGGL(large_extract_kernel, dim3(std::min<size_t>(cdiv(n_act, kBlock), 8192)), dim3(kBlock), 0, st2, avals, AG, adep,
                          n_act, d_ghead, d_large_id, d_large_off, d_rank, n, K1, LV0, LPOS);
       const int lgb = bit_length(n_large_groups > 0 ? n_large_groups - 1 : 0);
       const BitRange ranges[2] = {{0, rb}, {32, 32 + lgb}};
@@ -629,10 +630,10 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   if (n_text > 0) {
     static const int walk_dbg = getenv("WP_WALK_DBG") ? atoi(getenv("WP_WALK_DBG")) : 0;
     WalkArgs wa{d_cls, n_text, d_rank, steps, c->d_tok_len, hv.unk_id, d_emit, walk_dbg};
-    // the anchor list and the cleared emit array were produced on the side stream; the anchor count
-    // stays on the device, so the grid covers the worst case (every position an anchor)
-    hipLaunchKernelGGL(walk_kernel, dim3(cdiv(n_text, kBlock)), dim3(kBlock), 0, st, wa, d_anchors,
-                       c->d_scalars + 10, n_text);
+    // the anchor list and the cleared emit array were produced on the side stream; one lane per anchor
+    // (a grid sized for the worst case, every position an anchor, costs 0.35 ms of empty workgroups)
+    hipLaunchKernelGGL(walk_kernel, dim3(cdiv(std::max<size_t>(n_anchors, 1), kBlock)), dim3(kBlock), 0, st, wa,
+                       d_anchors, c->d_scalars + 10, std::max<size_t>(n_anchors, 1));
     const unsigned tiles = cdiv(n_text, kScanTile);
     hipLaunchKernelGGL(emit_count_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt);
     device_exclusive_scan(d_emit_cnt, d_emit_cnt, tiles, d_emit_tmp, c->d_scalars + 9, st);

@@ -32,18 +32,19 @@ __global__ __launch_bounds__(kBlock) void group_classify_kernel(const uint32_t *
                                                                 const uint32_t *__restrict__ n_groups_dev,
                                                                 uint32_t *__restrict__ large_flag,
                                                                 uint32_t *__restrict__ large_size, size_t cap) {
-  const size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (g >= cap) return;
-  uint32_t f = 0, sz = 0;
-  if (g < *n_groups_dev) {
+  // grid-stride over the groups that exist (the scans behind this kernel stop at n_groups too)
+  const size_t ng = min(cap, static_cast<size_t>(*n_groups_dev));
+  for (size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; g < ng;
+       g += static_cast<size_t>(gridDim.x) * kBlock) {
+    uint32_t f = 0, sz = 0;
     const uint32_t s = ghead[g + 1] - ghead[g];
     if (s > kLsMaxGroup) {
       f = 1;
       sz = s;
     }
+    large_flag[g] = f;
+    large_size[g] = sz;
   }
-  large_flag[g] = f;
-  large_size[g] = sz;
 }
 
 // entries of large groups -> (key, val, list position) in the large list
@@ -52,18 +53,19 @@ __global__ __launch_bounds__(kBlock) void large_extract_kernel(
     size_t m, const uint32_t *__restrict__ ghead, const uint32_t *__restrict__ large_id,
     const uint32_t *__restrict__ large_off, const RankEntry *__restrict__ rank, size_t n,
     uint64_t *__restrict__ lkey, uint32_t *__restrict__ lval, uint32_t *__restrict__ lpos) {
-  const size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (k >= m) return;
-  const uint32_t g = agid[k];
-  const uint32_t h0 = ghead[g];
-  if (ghead[g + 1] - h0 <= kLsMaxGroup) return;
-  const uint32_t j = large_off[g] + (static_cast<uint32_t>(k) - h0);
-  const uint32_t v = aval[k];
-  const size_t t = static_cast<size_t>(v) + adep[k];
-  const uint32_t r2 = t < n ? rank_of(rank[t]) + 1u : 0u;
-  lkey[j] = (static_cast<uint64_t>(large_id[g]) << 32) | r2;
-  lval[j] = v;
-  lpos[j] = static_cast<uint32_t>(k);
+  for (size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; k < m;
+       k += static_cast<size_t>(gridDim.x) * kBlock) {
+    const uint32_t g = agid[k];
+    const uint32_t h0 = ghead[g];
+    if (ghead[g + 1] - h0 <= kLsMaxGroup) continue;
+    const uint32_t j = large_off[g] + (static_cast<uint32_t>(k) - h0);
+    const uint32_t v = aval[k];
+    const size_t t = static_cast<size_t>(v) + adep[k];
+    const uint32_t r2 = t < n ? rank_of(rank[t]) + 1u : 0u;
+    lkey[j] = (static_cast<uint64_t>(large_id[g]) << 32) | r2;
+    lval[j] = v;
+    lpos[j] = static_cast<uint32_t>(k);
+  }
 }
 
 // sorted large list -> back to the list positions, with the original group id in the high word

@@ -205,7 +205,14 @@ __device__ __forceinline__ int32_t lcp_compare(const SymT *__restrict__ sym, siz
 
 // xcd != 0: workgroups of one XCD take a contiguous range of the list (used after the list has
 // been partitioned by destination, so that the stores of one XCD fall into one region and meet in
-// its L2)
+// its L2).  One entry per thread on purpose: the fewer entries an XCD has in flight, the narrower
+// the slice of the partitioned list it is working on and the better its stores merge (measured for
+// 1e8 entries: 0.79 ms with 1 entry per thread, 1.0 / 1.15 / 1.30 ms with 2 / 4 / 8).
+#ifndef WP_SP_ITEMS
+#define WP_SP_ITEMS 1
+#endif
+constexpr int kSpItems = WP_SP_ITEMS;
+constexpr int kSpTile = kBlock * kSpItems;
 __global__ __launch_bounds__(kBlock) void scatter_pairs_kernel(const uint32_t *__restrict__ dst,
                                                                const RankEntry *__restrict__ val, size_t m,
                                                                RankEntry *__restrict__ out, int xcd) {
@@ -214,10 +221,18 @@ __global__ __launch_bounds__(kBlock) void scatter_pairs_kernel(const uint32_t *_
     const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8;
     b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
   }
-  size_t k = static_cast<size_t>(b) * kBlock + threadIdx.x;
-  if (k < m) {
-    const RankEntry v = val[k];
-    if (v != kRankUnchanged) out[dst[k]] = v;
+  const size_t base = static_cast<size_t>(b) * kSpTile + threadIdx.x;
+  uint32_t d[kSpItems];
+  RankEntry v[kSpItems];
+#pragma unroll
+  for (int j = 0; j < kSpItems; j++) {
+    const size_t k = base + static_cast<size_t>(j) * kBlock;
+    v[j] = k < m ? val[k] : kRankUnchanged;
+    d[j] = k < m ? dst[k] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < kSpItems; j++) {
+    if (v[j] != kRankUnchanged) out[d[j]] = v[j];
   }
 }
 
