@@ -85,6 +85,9 @@ int wp_linear_encode_external(const char *text_file, const char *vocab_file, con
 #define WP_OPT_FUSED_RERANK 6 /* 1: single-pass group split (chained scan across tiles) instead of
                                  the default count / spine / apply kernels; same results, same
                                  speed on MI355X ("measured dead ends") */
+#define WP_OPT_COVER_ANCHORS 7 /* 1: always derive the walk's start positions from the matches
+                                 (default: only when the class rule leaves gaps > 2048 positions,
+                                 e.g. CJK text with multi-char CJK tokens) */
 int wp_set_option(wp_vocab *v, int option, int64_t value);
 
 /* ---- statistics of the last encode on this handle (for bench.py / roofline) ---- */
@@ -96,6 +99,8 @@ typedef struct {
   int64_t active_per_round[40];
   double ms_total, ms_decode, ms_sa, ms_lcp, ms_scan, ms_walk; /* WP_OPT_STAGE_TIMING */
   double ms_radix_scatter;    /* device time inside radix scatter kernels (HIP events) */
+  int64_t n_anchors;          /* start positions of the parallel walk                  */
+  int32_t anchor_mode;        /* 0: class rule, 1: coverage rule (WP_OPT_COVER_ANCHORS) */
 } wp_stats;
 int wp_get_stats(const wp_vocab *v, wp_stats *out);
 

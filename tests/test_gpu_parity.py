@@ -175,6 +175,71 @@ def test_fused_rerank_deep_prefix_8mb_ids():
     assert np.array_equal(ids, _oracle_ids_fast(text, vocab))
 
 
+def _cover_ids(text, vocab):
+    gv = W.Vocab(vocab)
+    gv.set_option(W.WP_OPT_COVER_ANCHORS, 1)
+    ids = gv.encode(text)
+    st = gv.stats()
+    assert st["anchor_mode"] == 1 or len(text) == 0 or st["n_text"] == 0
+    return ids
+
+
+def test_cover_anchors_forced_on_golden_and_random():
+    """WP_OPT_COVER_ANCHORS: the walk's start positions derived from the matches give the same ids."""
+    for name in ("reference_tests_cpp.json", "survey_probed_cases.json"):
+        for case in _load(name):
+            text = bytes.fromhex(case["text_hex"])
+            vocab = [bytes.fromhex(w) for w in case["vocab_hex"]]
+            exp = case["expected"] if case["expected"] is not None else O.Vocab(vocab).encode(text).tolist()
+            assert _cover_ids(text, vocab).tolist() == exp, case.get("name", name)
+    rng = random.Random(99)
+    alpha = "ab-, .c中"
+    done = 0
+    while done < 300:
+        vocab = set()
+        while len(vocab) < rng.randint(1, 8):
+            w = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 4)))
+            vocab.add("##" + w if rng.random() < 0.4 else w)
+        vocab = sorted(vocab)
+        text = "".join(rng.choice(alpha) for _ in range(rng.randint(0, 60)))
+        try:
+            ov = O.Vocab(vocab)
+        except O.OracleError:
+            continue
+        assert _cover_ids(text, vocab).tolist() == ov.encode(text).tolist(), repr((text, vocab))
+        done += 1
+    text, vocab = synth.english_corpus(2_000_000, seed=41, vocab_size=6000)
+    assert np.array_equal(_cover_ids(text, vocab), _oracle_ids_fast(text, vocab))
+
+
+def test_soft_spacing_chars_switch_to_cover_anchors():
+    """CJK text with multi-char CJK tokens: every spacing char is "soft", the class rule finds no
+    anchors, and the encoder must switch to the coverage rule by itself (a single lane would
+    otherwise walk the whole text)."""
+    rng = np.random.default_rng(5)
+    chars = [chr(c) for c in range(0x4E00, 0x4E00 + 300)]
+    words = ["".join(rng.choice(chars, size=int(k))) for k in rng.integers(1, 5, size=3000)]
+    vocab = ["[UNK]"] + chars[:280] + ["##" + c for c in chars[:280]] + list(dict.fromkeys(words[:1500]))
+    text = "".join(words[i] for i in rng.integers(0, len(words), size=60000)).encode("utf8")
+    gv = W.Vocab(vocab)
+    ids = gv.encode(text)
+    st = gv.stats()
+    assert st["anchor_mode"] == 1 and st["n_anchors"] > st["n_text"] // 64
+    assert np.array_equal(ids, O.Vocab(vocab).encode(text))
+    # mixed: an English block (dense class-rule anchors) in front of the CJK block
+    en, en_vocab = synth.english_corpus(300_000, seed=12, vocab_size=3000)
+    vocab2 = en_vocab + [w for w in vocab if w not in set(en_vocab)]
+    text2 = en + b"\n" + text
+    gv2 = W.Vocab(vocab2)
+    ids2 = gv2.encode(text2)
+    assert gv2.stats()["anchor_mode"] == 1
+    assert np.array_equal(ids2, O.Vocab(vocab2).encode(text2))
+    # plain English stays on the class rule
+    gv3 = W.Vocab(en_vocab)
+    gv3.encode(en)
+    assert gv3.stats()["anchor_mode"] == 0
+
+
 def test_kasai_kernel_gives_same_lcp():
     text, vocab = synth.english_corpus(300_000, seed=8, vocab_size=3000)
     d = O.Vocab(vocab).encode_debug(text)

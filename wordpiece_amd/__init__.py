@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WP_LIB") or os.path.join(_HERE, "libwordpiece_amd.so")
 
 WP_OPT_FULL_DEPTH, WP_OPT_DEVICE, WP_OPT_KEEP_DEBUG, WP_OPT_STAGE_TIMING, WP_OPT_LCP_KASAI = 1, 2, 3, 4, 5
-WP_OPT_FUSED_RERANK = 6
+WP_OPT_FUSED_RERANK, WP_OPT_COVER_ANCHORS = 6, 7
 
 # every symbol include/wordpiece_amd.h declares (checked by the CPU test-suite)
 ABI_SYMBOLS = [
@@ -43,7 +43,8 @@ class Stats(C.Structure):
                 ("radix_pass_elems", C.c_int64), ("radix_passes", C.c_int32),
                 ("active_per_round", C.c_int64 * 40),
                 ("ms_total", C.c_double), ("ms_decode", C.c_double), ("ms_sa", C.c_double), ("ms_lcp", C.c_double),
-                ("ms_scan", C.c_double), ("ms_walk", C.c_double), ("ms_radix_scatter", C.c_double)]
+                ("ms_scan", C.c_double), ("ms_walk", C.c_double), ("ms_radix_scatter", C.c_double),
+                ("n_anchors", C.c_int64), ("anchor_mode", C.c_int32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "active_per_round"}

@@ -115,7 +115,7 @@ struct wp_vocab {
   HostVocab hv;
   std::unique_ptr<Context> ctx;
   int device = -1;
-  bool full_depth = false, keep_debug = false, stage_timing = false, lcp_kasai = false, fused_rerank = false;
+  bool full_depth = false, keep_debug = false, stage_timing = false, lcp_kasai = false, fused_rerank = false, cover_anchors = false;
   wp_stats stats{};
   ~wp_vocab();
 };
@@ -434,12 +434,13 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   // workgroup (and of its neighbours on the same XCD) fall into one ~1/256 window of the rank table
   // and merge in that XCD's L2 (measured: 2.1 ms -> 1.0 ms for 1e8 stores).  t_dst/t_val: scratch.
   static const int bin_bits = getenv("WP_BIN_BITS") ? atoi(getenv("WP_BIN_BITS")) : 8;
+  static const int sp_lds = getenv("WP_SP_LDS") ? atoi(getenv("WP_SP_LDS")) : 0;  // occupancy experiment
   auto store_ranks = [&](uint32_t *dst, uint32_t *val, uint32_t *t_dst, uint32_t *t_val, size_t m) {
     if (bin_bits > 0 && m >= (1u << 22)) {
       const int hb = bit_length(n - 1);
       const int bc = radix_sort_pairs<uint32_t>(dst, val, t_dst, t_val, m, std::max(0, hb - bin_bits), hb, d_radix_tmp,
                                                 st, nullptr);
-      hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, bc ? t_dst : dst,
+      hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), sp_lds, st, bc ? t_dst : dst,
                          bc ? t_val : val, m, d_rank, 1);
     } else {
       hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, dst, val, m, d_rank, 0);
@@ -457,10 +458,13 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     fork();
     const unsigned atiles = cdiv(n_text, kAnchorTile);
     WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st2));
-    hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls, n_text, d_anchor_cnt);
+    hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls,
+                       static_cast<const uint8_t *>(nullptr), n_text, d_anchor_cnt);
     device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st2);
-    hipLaunchKernelGGL(anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls, n_text, d_anchor_cnt,
-                       d_anchors);
+    hipLaunchKernelGGL(anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls,
+                       static_cast<const uint8_t *>(nullptr), n_text, d_anchor_cnt, d_anchors);
+    hipLaunchKernelGGL(anchor_gap_kernel, dim3(std::min<size_t>(atiles, 1024)), dim3(kBlock), 0, st2, d_anchors,
+                       c->d_scalars + 10, n_text, c->d_scalars + 11);
   }
   // group split of a round: count / spine / apply kernels, or (WP_OPT_FUSED_RERANK, env WP_RERANK=fused)
   // one kernel with a chained scan across tiles
@@ -499,10 +503,23 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     classified = classify_groups(n);
     join();
   }
-  fetch_scalars(c, 11);
-  const size_t n_anchors = n_text > 0 ? c->h_scalars[10] : 0;  // (the side stream was joined above)
+  fetch_scalars(c, 12);
+  size_t n_anchors = n_text > 0 ? c->h_scalars[10] : 0;  // (the side stream was joined above)
+  const size_t max_anchor_gap = n_text > 0 ? c->h_scalars[11] : 0;
   size_t n_act = c->h_scalars[4], n_groups = c->h_scalars[5];
   size_t n_large_groups = classified ? c->h_scalars[6] : 0, n_large = classified ? c->h_scalars[7] : 0;
+  static const bool group_stats = getenv("WP_GROUP_STATS") && atoi(getenv("WP_GROUP_STATS")) != 0;
+  if (group_stats && n_groups > 0) {  // tuning aid: active entries by group size class after round 0
+    unsigned long long *d_gs = reinterpret_cast<unsigned long long *>(d_tdep), h_gs[18];
+    WP_HIP(hipMemsetAsync(d_gs, 0, sizeof(h_gs), st));
+    hipLaunchKernelGGL(group_stats_kernel, dim3(cdiv(n_groups, kBlock)), dim3(kBlock), 0, st, d_ghead,
+                       static_cast<uint32_t>(n_groups), d_gs);
+    WP_HIP(hipMemcpyAsync(h_gs, d_gs, sizeof(h_gs), hipMemcpyDeviceToHost, st));
+    WP_HIP(hipStreamSynchronize(st));
+    static const char *cls[9] = {"2", "3-4", "5-8", "9-16", "17-32", "33-64", "65-256", "257-2048", ">2048"};
+    std::cerr << "group stats after round 0: n_act=" << n_act << " groups=" << n_groups << "\n";
+    for (int i = 0; i < 9; i++) std::cerr << "  size " << cls[i] << ": entries " << h_gs[i] << " groups " << h_gs[9 + i] << "\n";
+  }
   int rounds = 1;
   S.active_per_round[0] = static_cast<int64_t>(n);
   uint32_t *avals = other_vals;  // active list values live in the vals buffer the sort did not end in
@@ -628,8 +645,30 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   int32_t *d_ids = reinterpret_cast<int32_t *>(V1);
   size_t n_ids = 0;
   if (n_text > 0) {
-    static const int walk_dbg = getenv("WP_WALK_DBG") ? atoi(getenv("WP_WALK_DBG")) : 0;
-    WalkArgs wa{d_cls, n_text, d_rank, steps, c->d_tok_len, hv.unk_id, d_emit, walk_dbg};
+    WalkArgs wa{d_cls, n_text, d_rank, steps, c->d_tok_len, hv.unk_id, d_emit, nullptr};
+    S.anchor_mode = 0;
+    if (v->cover_anchors || max_anchor_gap > kMaxAnchorGap) {
+      // long stretches without class-rule anchors ("soft" spacing chars): anchors from the matches
+      // themselves (walk.h).  The large-group buffers of the suffix sort are free by now.
+      uint32_t *d_reach = LV0, *d_reach_tiles = LPOS;
+      uint8_t *d_aflags = reinterpret_cast<uint8_t *>(LV1);
+      const unsigned rtiles = cdiv(n_text, kReachTile), atiles = cdiv(n_text, kAnchorTile);
+      hipLaunchKernelGGL(reach_kernel, dim3(rtiles), dim3(kBlock), 0, st, wa, d_reach, d_reach_tiles);
+      hipLaunchKernelGGL(reach_spine_kernel, dim3(1), dim3(1024), 0, st, d_reach_tiles, static_cast<size_t>(rtiles));
+      hipLaunchKernelGGL(cover_flags_kernel, dim3(rtiles), dim3(kBlock), 0, st, d_cls, d_reach, d_reach_tiles, n_text,
+                         d_aflags);
+      hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, d_aflags, n_text,
+                         d_anchor_cnt);
+      device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st);
+      hipLaunchKernelGGL(anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, d_aflags, n_text,
+                         d_anchor_cnt, d_anchors);
+      WP_LAUNCH_CHECK();
+      fetch_scalars(c, 11);
+      n_anchors = c->h_scalars[10];
+      wa.aflags = d_aflags;
+      S.anchor_mode = 1;
+    }
+    S.n_anchors = static_cast<int64_t>(n_anchors);
     // the anchor list and the cleared emit array were produced on the side stream; one lane per anchor
     // (a grid sized for the worst case, every position an anchor, costs 0.35 ms of empty workgroups)
     hipLaunchKernelGGL(walk_kernel, dim3(cdiv(std::max<size_t>(n_anchors, 1), kBlock)), dim3(kBlock), 0, st, wa,
@@ -772,6 +811,7 @@ int wp_set_option(wp_vocab *v, int option, int64_t value) {
     case WP_OPT_STAGE_TIMING: v->stage_timing = value != 0; return WP_OK;
     case WP_OPT_LCP_KASAI: v->lcp_kasai = value != 0; return WP_OK;
     case WP_OPT_FUSED_RERANK: v->fused_rerank = value != 0; return WP_OK;
+    case WP_OPT_COVER_ANCHORS: v->cover_anchors = value != 0; return WP_OK;
   }
   g_last_error = "unknown option";
   return WP_ERR_ARG;

@@ -103,6 +103,11 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
   for (int j = 0; j < ITEMS; j++) {
     const size_t i = base + static_cast<size_t>(j) * kWave + lane;
     const uint32_t d = static_cast<uint32_t>(key[j] >> begin_bit) & mask;
+#if defined(WP_HIST_NOCOUNT)  // probe only (profiles/tools/hist_probe.hip): loads without counting
+    if (i < n && d == 0x1ffu) sh[w][0] = 1;
+#elif defined(WP_HIST_ATOMIC)
+    if (i < n) atomicAdd(&sh[w][d], 1u);
+#else
     uint32_t plo, phi;
     wave_match_any<kRadixBits>(d, plo, phi);
     const uint64_t valid = __ballot(i < n);  // lanes past the end (last tile only) are not counted
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
     phi &= static_cast<uint32_t>(valid >> 32);
     const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
     if (below == 0 && i < n) mycnt[d] = mycnt[d] + __popc(plo) + __popc(phi);
+#endif
   }
   __syncthreads();
 #pragma unroll

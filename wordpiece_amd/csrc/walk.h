@@ -25,7 +25,7 @@ struct WalkArgs {
   const int32_t *tok_len;
   int32_t unk_id;
   int32_t *emit;
-  int dbg;  // timing experiments only (WP_WALK_DBG): 1 = no emit stores, 2 = no step lookup, 4 = no rank load
+  const uint8_t *aflags;  // != nullptr: anchors are given per position (coverage-based anchors, below)
 };
 
 __device__ __forceinline__ bool w_space(const WalkArgs &a, size_t p) { return a.cls[p] & kClsSpace; }
@@ -34,6 +34,7 @@ __device__ __forceinline__ bool w_word_prefix(const WalkArgs &a, size_t p) {  //
 }
 __device__ __forceinline__ bool w_hard(uint8_t c) { return (c & kClsSpacing) && !(c & kClsSoft); }
 __device__ __forceinline__ bool w_anchor(const WalkArgs &a, size_t p) {
+  if (a.aflags) return a.aflags[p] != 0;
   const uint8_t c = a.cls[p];
   if (c & kClsSpace) return false;
   return p == 0 || w_hard(c) || w_hard(a.cls[p - 1]);
@@ -44,11 +45,11 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
   size_t since = p;  // start of the tokens counted by tokens_since_prefix
   while (p < end) {
     const bool prefix = w_word_prefix(a, p);
-    const uint32_t r = (a.dbg & 4) ? static_cast<uint32_t>(p) : rank_of(a.rank[p]);
-    const int k = (a.dbg & 2) ? 0 : step_lookup(a.steps, r);
-    const int32_t id = (a.dbg & 2) ? static_cast<int32_t>(5 + (r & 63)) : (prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k]);
+    const uint32_t r = rank_of(a.rank[p]);
+    const int k = step_lookup(a.steps, r);
+    const int32_t id = prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
     if (id != -1) {
-      if (!(a.dbg & 1)) a.emit[p] = id;
+      a.emit[p] = id;
       p += static_cast<size_t>(a.tok_len[id]);
       if (p < end && w_word_prefix(a, p)) since = p;
     } else {
@@ -79,9 +80,11 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
 constexpr int kAnchorBytes = 16;
 constexpr int kAnchorTile = kBlock * kAnchorBytes;  // 4096 positions per workgroup
 
-__device__ __forceinline__ uint32_t anchor_mask16(const uint8_t *__restrict__ cls, size_t n, size_t i) {
+__device__ __forceinline__ uint32_t anchor_mask16(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ aflags,
+                                                  size_t n, size_t i) {
   if (i >= n) return 0u;
   uint32_t w[4];
+  if (aflags) cls = aflags;  // per-position flags (0/1) instead of the class rule
   if (i + kAnchorBytes <= n) {
     const uint4 v = *reinterpret_cast<const uint4 *>(cls + i);  // cls is 256-byte aligned, i a multiple of 16
     w[0] = v.x;
@@ -99,6 +102,14 @@ __device__ __forceinline__ uint32_t anchor_mask16(const uint8_t *__restrict__ cl
       }
     }
   }
+  uint32_t valid = 0xffffu;
+  if (i + kAnchorBytes > n) valid = (1u << (n - i)) - 1u;
+  if (aflags) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) m |= (((w[q] & 0x01010101u) * 0x01020408u) >> 24) << (4 * q);
+    return m & valid;
+  }
   uint32_t space = 0, hard = 0;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -110,34 +121,142 @@ __device__ __forceinline__ uint32_t anchor_mask16(const uint8_t *__restrict__ cl
   }
   uint32_t before = 1u;  // position 0 counts as preceded by a hard boundary
   if (i > 0) before = w_hard(cls[i - 1]) ? 1u : 0u;
-  uint32_t valid = 0xffffu;
-  if (i + kAnchorBytes > n) valid = (1u << (n - i)) - 1u;
   return ~space & (hard | (hard << 1) | before) & valid;
 }
 
-__global__ __launch_bounds__(kBlock) void anchor_count_kernel(const uint8_t *__restrict__ cls, size_t n,
+__global__ __launch_bounds__(kBlock) void anchor_count_kernel(const uint8_t *__restrict__ cls,
+                                                              const uint8_t *__restrict__ aflags, size_t n,
                                                               uint32_t *__restrict__ tile_counts) {
   __shared__ uint32_t sm[8];
   const size_t i = static_cast<size_t>(blockIdx.x) * kAnchorTile + static_cast<size_t>(threadIdx.x) * kAnchorBytes;
-  const uint32_t c = __popc(anchor_mask16(cls, n, i));
+  const uint32_t c = __popc(anchor_mask16(cls, aflags, n, i));
   uint32_t tot;
   (void)block_excl_sum(c, sm, tot);
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
 }
 
 // the list stays in text order: lane offsets come from a workgroup scan of the per-lane counts
-__global__ __launch_bounds__(kBlock) void anchor_write_kernel(const uint8_t *__restrict__ cls, size_t n,
+__global__ __launch_bounds__(kBlock) void anchor_write_kernel(const uint8_t *__restrict__ cls,
+                                                              const uint8_t *__restrict__ aflags, size_t n,
                                                               const uint32_t *__restrict__ tile_prefix,
                                                               uint32_t *__restrict__ anchors) {
   __shared__ uint32_t sm[8];
   const size_t i = static_cast<size_t>(blockIdx.x) * kAnchorTile + static_cast<size_t>(threadIdx.x) * kAnchorBytes;
-  uint32_t m = anchor_mask16(cls, n, i);
+  uint32_t m = anchor_mask16(cls, aflags, n, i);
   uint32_t tot;
   uint32_t o = tile_prefix[blockIdx.x] + block_excl_sum(static_cast<uint32_t>(__popc(m)), sm, tot);
   while (m) {
     const int j = __ffs(static_cast<int>(m)) - 1;
     m &= m - 1;
     anchors[o++] = static_cast<uint32_t>(i + j);
+  }
+}
+
+// ---- coverage-based anchors --------------------------------------------------------------------
+// The class rule above yields no anchors inside text whose spacing chars are all "soft" (e.g. CJK
+// text with a vocabulary that holds multi-char CJK tokens): one lane would walk the whole stretch.
+// The encoder measures the largest gap between anchors and, if it is long, derives the anchors from
+// the matches themselves.  The walk's position sequence is a function of the position alone: from q
+// it moves by len(best token at q), or (no token) to the next word-prefix position, then over
+// spaces.  So a non-space word-prefix position p that no match starting before it reaches across
+// (max over q < p of q + len(q) <= p) is always landed on, with the per-word state reset — exactly
+// what an anchor needs.  Cost: one match lookup per text position instead of one per visited one.
+__global__ __launch_bounds__(kBlock) void anchor_gap_kernel(const uint32_t *__restrict__ anchors,
+                                                            const uint32_t *__restrict__ n_anchors_dev, size_t n_text,
+                                                            uint32_t *__restrict__ max_gap) {
+  __shared__ int32_t sm[8];
+  const size_t na = *n_anchors_dev;
+  uint32_t g = 0;
+  for (size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; k <= na;
+       k += static_cast<size_t>(gridDim.x) * kBlock) {
+    const uint32_t hi = k < na ? anchors[k] : static_cast<uint32_t>(n_text);
+    const uint32_t lo = k > 0 ? anchors[k - 1] : 0u;
+    g = max(g, hi - lo);
+  }
+  const int32_t m = -block_reduce_min(-static_cast<int32_t>(g), sm);
+  if (threadIdx.x == 0 && m > 0) atomicMax(max_gap, static_cast<uint32_t>(m));
+}
+
+constexpr int kReachTile = kBlock * 8;
+constexpr size_t kMaxAnchorGap = 2048;  // longer gaps between class-rule anchors switch the anchor rule
+
+// reach[q] = q + length of the token the walk would take at q (q itself: none, or a space)
+__global__ __launch_bounds__(kBlock) void reach_kernel(WalkArgs a, uint32_t *__restrict__ reach,
+                                                       uint32_t *__restrict__ tile_max) {
+  __shared__ int32_t sm[8];
+  const size_t base = static_cast<size_t>(blockIdx.x) * kReachTile;
+  uint32_t mx = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const size_t q = base + static_cast<size_t>(j) * kBlock + threadIdx.x;
+    if (q < a.n_text) {
+      uint32_t r = static_cast<uint32_t>(q);
+      if (!w_space(a, q)) {
+        const int k = step_lookup(a.steps, rank_of(a.rank[q]));
+        const int32_t id = w_word_prefix(a, q) ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
+        if (id != -1) r += static_cast<uint32_t>(a.tok_len[id]);
+      }
+      reach[q] = r;
+      mx = max(mx, r);
+    }
+  }
+  const int32_t m = -block_reduce_min(-static_cast<int32_t>(mx), sm);
+  if (threadIdx.x == 0) tile_max[blockIdx.x] = static_cast<uint32_t>(m);
+}
+
+// in place: tile_max[t] <- max over tiles before t (single workgroup)
+__global__ __launch_bounds__(1024) void reach_spine_kernel(uint32_t *__restrict__ tile_max, size_t tiles) {
+  __shared__ int32_t wm[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int32_t carry = 0;
+  for (size_t base = 0; base < tiles; base += 1024) {
+    const size_t i = base + threadIdx.x;
+    const int32_t v = i < tiles ? static_cast<int32_t>(tile_max[i]) : 0;
+    const int32_t inc = wave_incl_max(v);
+    if (lane == kWave - 1) wm[w] = inc;
+    __syncthreads();
+    int32_t before = carry, all = carry;
+    for (int q = 0; q < 16; q++) {
+      if (q < w) before = max(before, wm[q]);
+      all = max(all, wm[q]);
+    }
+    const int32_t up = __shfl_up(inc, 1, kWave);
+    if (i < tiles) tile_max[i] = static_cast<uint32_t>(lane == 0 ? before : max(before, up));
+    carry = all;
+    __syncthreads();
+  }
+}
+
+// aflags[p] = 1 iff p is a non-space word-prefix position that no earlier match reaches across
+__global__ __launch_bounds__(kBlock) void cover_flags_kernel(const uint8_t *__restrict__ cls,
+                                                             const uint32_t *__restrict__ reach,
+                                                             const uint32_t *__restrict__ tile_before, size_t n,
+                                                             uint8_t *__restrict__ aflags) {
+  __shared__ int32_t wm[4];
+  const int lane = lane_id(), w = wave_id();
+  const size_t p0 = static_cast<size_t>(blockIdx.x) * kReachTile + static_cast<size_t>(threadIdx.x) * 8;
+  int32_t r[8], mx = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    r[j] = p0 + j < n ? static_cast<int32_t>(reach[p0 + j]) : 0;
+    mx = max(mx, r[j]);
+  }
+  const int32_t inc = wave_incl_max(mx);
+  if (lane == kWave - 1) wm[w] = inc;
+  __syncthreads();
+  int32_t cover = static_cast<int32_t>(tile_before[blockIdx.x]);  // reach of everything before this thread
+  for (int q = 0; q < w; q++) cover = max(cover, wm[q]);
+  const int32_t up = __shfl_up(inc, 1, kWave);
+  if (lane > 0) cover = max(cover, up);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const size_t p = p0 + j;
+    if (p < n) {
+      const uint8_t c = cls[p];
+      const bool wp = p == 0 || (c & kClsSpacing) || (cls[p - 1] & kClsSpacing);
+      aflags[p] = (!(c & kClsSpace) && wp && cover <= static_cast<int32_t>(p)) ? 1 : 0;
+      cover = max(cover, r[j]);
+    }
   }
 }
 

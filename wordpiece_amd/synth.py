@@ -170,10 +170,14 @@ def multilingual_corpus(n_bytes, seed=0, vocab_size=120000):
     return np.concatenate(blocks).tobytes(), vocab
 
 
-def deep_prefix_corpus(n_bytes, seed=0, word_len=512, n_stems=128, suffix_stems=16, suffix_len=128):
-    """Config 5: words = stem_k[:m] + stem_j[:word_len-m]; vocab = every proper prefix of every stem."""
+def deep_prefix_corpus(n_bytes, seed=0, word_len=512, n_stems=128, suffix_stems=16, suffix_len=128,
+                       words_seed=None):
+    """Config 5: words = stem_k[:m] + stem_j[:word_len-m]; vocab = every proper prefix of every stem.
+    words_seed: draw the words from a separate stream (same stems and vocab, different text)."""
     rng = np.random.default_rng(seed)
     stems = rng.integers(97, 123, size=(n_stems, word_len)).astype(np.uint8)
+    if words_seed is not None:
+        rng = np.random.default_rng([seed, words_seed])
     vocab = ["[UNK]"] + ["##" + chr(c) for c in range(97, 123)]
     for k in range(n_stems):
         s = stems[k].tobytes().decode()
