@@ -183,7 +183,8 @@ def main():
         value = total_bytes / 1e6 / (dt_max / args.steps)
         # dominant kernel: the radix scatter pass; algorithmic bytes = 24 B per element moved
         avg_launch_ms = radix_ms / max(radix_launches, 1)
-        avg_launch_bytes = RADIX_BYTES_PER_ELEM * radix_elems / max(radix_launches, 1)
+        # (the first pass of the round-0 sort makes the index column up instead of reading it: -4 B per symbol)
+        avg_launch_bytes = (RADIX_BYTES_PER_ELEM * radix_elems - 4 * st["n_total"] * args.steps) / max(radix_launches, 1)
         achieved = avg_launch_bytes / 1e9 / (avg_launch_ms / 1e3) if avg_launch_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "radix_scatter_traffic.json")

@@ -44,7 +44,7 @@ class Stats(C.Structure):
                 ("active_per_round", C.c_int64 * 40),
                 ("ms_total", C.c_double), ("ms_decode", C.c_double), ("ms_sa", C.c_double), ("ms_lcp", C.c_double),
                 ("ms_scan", C.c_double), ("ms_walk", C.c_double), ("ms_radix_scatter", C.c_double),
-                ("n_anchors", C.c_int64), ("anchor_mode", C.c_int32)]
+                ("n_anchors", C.c_int64), ("anchor_mode", C.c_int32), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "active_per_round"}

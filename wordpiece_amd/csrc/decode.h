@@ -259,8 +259,7 @@ constexpr int kKeyHalo = 64;
 __device__ __forceinline__ int key_pad(int p) { return p + (p >> 3); }
 template <typename SymT>
 __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restrict__ sym, size_t n, DevCode code,
-                                                             uint64_t *__restrict__ keys,
-                                                             uint32_t *__restrict__ vals) {
+                                                             uint64_t *__restrict__ keys) {
   constexpr int kSymSlots = kKeyTile + kKeyHalo;
   __shared__ uint32_t ss[kSymSlots + kSymSlots / 8 + 1];
   __shared__ uint32_t stab[256];  // (len << 16) | codeword
@@ -304,8 +303,7 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
     const int li = j * kBlock + threadIdx.x;
     const size_t i = base + li;
     if (i < n) {
-      keys[i] = skey[key_pad(li)];
-      vals[i] = static_cast<uint32_t>(i);
+      keys[i] = skey[key_pad(li)];  // (the values, 0..n-1, are made up by the first radix pass)
     }
   }
 }

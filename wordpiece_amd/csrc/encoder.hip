@@ -10,6 +10,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -412,7 +413,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   }
   S.symbols_per_key = static_cast<int32_t>(kKeyBits / std::max(1.0, code.avg_bits));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(build_keys0_kernel<SymT>), dim3(cdiv(n, kKeyTile)), dim3(kBlock), 0, st, d_sym,
-                     n, dcode, K0, V0);
+                     n, dcode, K0);
   WP_LAUNCH_CHECK();
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[2], st));
 
@@ -446,7 +447,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, dst, val, m, d_rank, 0);
     }
   };
-  int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, kKeyBits, d_radix_tmp, st, &c->rstats);
+  int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, kKeyBits, d_radix_tmp, st, &c->rstats, true);
   uint64_t *keys = cur ? K1 : K0;
   uint32_t *vals = cur ? V1 : V0, *other_vals = cur ? V0 : V1;
   uint32_t *slots = AS0, *other_slots = AS1;
@@ -840,9 +841,15 @@ int wp_linear_encode(wp_vocab *v, const char *utf8, size_t nbytes, int32_t **ids
     Context *c = get_context(v);
     c->text_buf.ensure(nbytes + 64);
     WP_HIP(hipMemsetAsync(static_cast<char *>(c->text_buf.p) + (nbytes & ~static_cast<size_t>(15)), 0, 32, c->stream));
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    auto t0 = clk::now();
     WP_HIP(hipMemcpyAsync(c->text_buf.p, utf8, nbytes, hipMemcpyHostToDevice, c->stream));
+    if (v->stage_timing) WP_HIP(hipStreamSynchronize(c->stream));
+    const double ms_h2d = ms_since(t0);
     size_t n = 0;
     encode_on_device(v, static_cast<const uint8_t *>(c->text_buf.p), nbytes, &n);
+    t0 = clk::now();
     if (n) {
       int32_t *h = static_cast<int32_t *>(std::malloc(n * sizeof(int32_t)));
       if (!h) throw std::runtime_error("out of host memory");
@@ -851,6 +858,8 @@ int wp_linear_encode(wp_vocab *v, const char *utf8, size_t nbytes, int32_t **ids
       *ids = h;
       *n_ids = n;
     }
+    v->stats.ms_h2d = v->stage_timing ? ms_h2d : 0.0;
+    v->stats.ms_d2h = ms_since(t0);
   });
 }
 

@@ -17,8 +17,14 @@
 
 namespace wp {
 
-constexpr int kLsT = 2048;                // nominal list entries per workgroup
-constexpr int kLsMaxGroup = 2048;         // groups above this size use the global path
+#ifndef WP_LS_T
+#define WP_LS_T 2048
+#endif
+#ifndef WP_LS_MAXGROUP
+#define WP_LS_MAXGROUP 2048
+#endif
+constexpr int kLsT = WP_LS_T;                // nominal list entries per workgroup
+constexpr int kLsMaxGroup = WP_LS_MAXGROUP;  // groups above this size use the global path
 constexpr int kLsCap = kLsT + kLsMaxGroup;  // LDS capacity in entries
 constexpr int kLsItems = kLsCap / kBlock;   // 16
 constexpr int kLsBits = 10;

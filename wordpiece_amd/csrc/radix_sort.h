@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
     const bool valid = i < n;
     key[r] = valid ? kin[i] : static_cast<KeyT>(~static_cast<KeyT>(0));
-    val[r] = valid ? vin[i] : 0u;
+    val[r] = valid ? (vin ? vin[i] : static_cast<uint32_t>(i)) : 0u;  // vin == nullptr: the identity
   }
   volatile uint32_t *mycnt = wcnt[w];
 #pragma unroll
@@ -364,9 +364,10 @@ struct BitRange {
 // Sorts the given bit ranges of the keys, least significant range first (stable LSD).  Data
 // ping-pongs between (k0,v0) and (k1,v1); returns 0 or 1 = which pair holds the result.
 // tmp: radix_tmp_words<KeyT>(n) uint32.
+// identity_vals: the input values are 0..n-1 and v0 need not hold them (the first pass makes them up)
 template <typename KeyT>
 int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, const BitRange *ranges,
-                      int nranges, uint32_t *tmp, hipStream_t st, RadixStats *stats) {
+                      int nranges, uint32_t *tmp, hipStream_t st, RadixStats *stats, bool identity_vals = false) {
   int cur = 0;
   if (n == 0) return cur;
   const unsigned ntiles = cdiv(n, RadixCfg<KeyT>::kTile);
@@ -390,8 +391,9 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
       hipLaunchKernelGGL(radix_spine_kernel, dim3(1), dim3(kSpineThreads), 0, st, chunk_sums, chunk_pre, nchunks);
       hipLaunchKernelGGL(radix_apply_kernel, dim3(nchunks), dim3(kRadixBins), 0, st, table, chunk_pre, ntiles);
       if (stats) stats->spans.begin(st);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, vi, ko,
-                         vo, n, b, mask, table);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki,
+                         identity_vals ? static_cast<const uint32_t *>(nullptr) : vi, ko, vo, n, b, mask, table);
+      identity_vals = false;
       WP_LAUNCH_CHECK();
       if (stats) {
         stats->spans.end(st);
@@ -406,9 +408,9 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
 
 template <typename KeyT>
 int radix_sort_pairs(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, int begin_bit, int end_bit,
-                     uint32_t *tmp, hipStream_t st, RadixStats *stats) {
+                     uint32_t *tmp, hipStream_t st, RadixStats *stats, bool identity_vals = false) {
   BitRange r{begin_bit, end_bit};
-  return radix_sort_ranges<KeyT>(k0, v0, k1, v1, n, &r, 1, tmp, st, stats);
+  return radix_sort_ranges<KeyT>(k0, v0, k1, v1, n, &r, 1, tmp, st, stats, identity_vals);
 }
 
 }  // namespace wp
