@@ -12,6 +12,7 @@ There is no CPU fallback: without the built extension or without a GPU every cal
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -149,11 +150,7 @@ class Vocab:
         ids = C.POINTER(C.c_int32)()
         n = C.c_size_t()
         _check(lib().wp_linear_encode(self._h, b, len(b), C.byref(ids), C.byref(n)))
-        if n.value == 0:
-            return np.zeros(0, dtype=np.int32)
-        out = np.ctypeslib.as_array(ids, shape=(n.value,)).copy()
-        lib().wp_free(ids)
-        return out
+        return _adopt_ids(ids, n.value)
 
     def encode_device(self, d_ptr, nbytes):
         """Text already in HBM at `d_ptr` -> (device pointer of int32 ids, count).  The id buffer is
@@ -171,6 +168,16 @@ class Vocab:
         return out[:n.value]
 
 
+def _adopt_ids(ids, n):
+    """numpy view of the malloc'd id buffer the library returned (no copy); wp_free runs when the
+    array (and every view of it) is gone."""
+    if n == 0:
+        return np.zeros(0, dtype=np.int32)
+    out = np.ctypeslib.as_array(ids, shape=(n,))
+    weakref.finalize(out.base if out.base is not None else out, lib().wp_free, ids)  # the bottom of the view chain
+    return out
+
+
 class _Linear:
     """word_piece::linear of the reference (src/word_piece.hpp:10-21)."""
 
@@ -180,10 +187,7 @@ class _Linear:
             ids = C.POINTER(C.c_int32)()
             n = C.c_size_t()
             _check(lib().wp_linear_encode_file(_bytes(text), _bytes(vocab), C.byref(ids), C.byref(n)))
-            out = np.ctypeslib.as_array(ids, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int32)
-            if n.value:
-                lib().wp_free(ids)
-            return out.tolist()
+            return _adopt_ids(ids, n.value).tolist()
         return Vocab(vocab).encode(text).tolist()  # linear.cpp:332-335
 
     @staticmethod

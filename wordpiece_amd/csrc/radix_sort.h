@@ -35,7 +35,13 @@ struct RadixCfg {
 #endif
   static constexpr int kItems = sizeof(KeyT) == 8 ? WP_RADIX_ITEMS64 : 16;
   static constexpr int kTile = kBlock * kItems;
+  // Inputs of up to kSmallN elements (mark / step lists, the large groups of a doubling round) use
+  // tiles of kSmallItems per thread: a 5120-key tile takes ~70 us from first load to last store, and
+  // with less than one tile per CU that latency is the whole pass.
+  static constexpr int kSmallItems = 4;
+  static constexpr int kSmallTile = kBlock * kSmallItems;
 };
+constexpr size_t kRadixSmallN = size_t(1) << 21;
 
 // Lanes of the wave holding the same digit, as (mismatch_lo, mismatch_hi) complemented.  Per digit
 // bit: one ballot, and "my bit differs from lane l's bit" = ballot ^ sign-extended(my bit), OR-ed
@@ -74,12 +80,11 @@ __device__ __forceinline__ uint32_t wave_rank_digit(volatile uint32_t *cnt, uint
 // prefixes in (digit, tile) order; the apply kernel rewrites every row as global offsets.
 constexpr int kColChunk = 64;
 
-template <typename KeyT>
+template <typename KeyT, int ITEMS>
 __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restrict__ keys, size_t n,
                                                             int begin_bit, uint32_t mask,
                                                             uint32_t *__restrict__ table,
                                                             uint32_t *__restrict__ chunk_sums) {
-  constexpr int ITEMS = RadixCfg<KeyT>::kItems;
   constexpr int WAVES = kBlock / kWave;
   // per-wave counters, bumped once per distinct digit of a wave round by its lowest lane (match-any):
   // no LDS atomics, no same-address serialisation on skewed digits
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   volatile uint32_t *mycnt = sh[w];
-  const size_t base = static_cast<size_t>(blockIdx.x) * RadixCfg<KeyT>::kTile + static_cast<size_t>(w) * (kWave * ITEMS);
+  const size_t base = static_cast<size_t>(blockIdx.x) * (kBlock * ITEMS) + static_cast<size_t>(w) * (kWave * ITEMS);
   KeyT key[ITEMS];
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
@@ -210,13 +215,12 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned ntiles) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
 }
 
-template <typename KeyT>
+template <typename KeyT, int ITEMS>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
     uint32_t *__restrict__ vout, size_t n, int begin_bit, uint32_t mask,
     const uint32_t *__restrict__ goff) {
-  constexpr int ITEMS = RadixCfg<KeyT>::kItems;
-  constexpr int TILE = RadixCfg<KeyT>::kTile;
+  constexpr int TILE = kBlock * ITEMS;
   constexpr int WAVES = kBlock / kWave;
   __shared__ uint32_t wcnt[WAVES][kRadixBins];
   __shared__ uint32_t dstart[kRadixBins];
@@ -352,7 +356,9 @@ constexpr int kMaxZeroedPasses = 8;  // chunk-sum tables cleared by one memset p
 
 template <typename KeyT>
 size_t radix_tmp_words(size_t n) {
-  size_t ntiles = cdiv(n, RadixCfg<KeyT>::kTile);
+  // (monotone in n: covers the small-tile configuration of every input size up to n as well)
+  const size_t ntiles = std::max<size_t>(cdiv(n, RadixCfg<KeyT>::kTile),
+                                         cdiv(std::min(n, kRadixSmallN), RadixCfg<KeyT>::kSmallTile));
   size_t h = ntiles * kRadixBins;
   return h + (kMaxZeroedPasses + 1) * (cdiv(ntiles, kColChunk) + 1) * kRadixBins + 64;
 }
@@ -370,7 +376,9 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
                       int nranges, uint32_t *tmp, hipStream_t st, RadixStats *stats, bool identity_vals = false) {
   int cur = 0;
   if (n == 0) return cur;
-  const unsigned ntiles = cdiv(n, RadixCfg<KeyT>::kTile);
+  const bool small = n <= kRadixSmallN;
+  if (small) stats = nullptr;  // the roofline statistics describe the full-size configuration only
+  const unsigned ntiles = cdiv(n, small ? RadixCfg<KeyT>::kSmallTile : RadixCfg<KeyT>::kTile);
   const unsigned nchunks = cdiv(ntiles, kColChunk);
   const size_t h = static_cast<size_t>(ntiles) * kRadixBins;
   const size_t cs_words = static_cast<size_t>(nchunks + 1) * kRadixBins;
@@ -386,13 +394,24 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
       uint32_t *chunk_sums = chunk_sums0 + cs_words * static_cast<size_t>(pass % kMaxZeroedPasses);
       if (pass >= kMaxZeroedPasses) WP_HIP(hipMemsetAsync(chunk_sums, 0, sizeof(uint32_t) * cs_words, st));
       pass++;
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki, n, b, mask,
-                         table, chunk_sums);
+      if (small) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT, RadixCfg<KeyT>::kSmallItems>), dim3(ntiles),
+                           dim3(kBlock), 0, st, ki, n, b, mask, table, chunk_sums);
+      } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT, RadixCfg<KeyT>::kItems>), dim3(ntiles),
+                           dim3(kBlock), 0, st, ki, n, b, mask, table, chunk_sums);
+      }
       hipLaunchKernelGGL(radix_spine_kernel, dim3(1), dim3(kSpineThreads), 0, st, chunk_sums, chunk_pre, nchunks);
       hipLaunchKernelGGL(radix_apply_kernel, dim3(nchunks), dim3(kRadixBins), 0, st, table, chunk_pre, ntiles);
       if (stats) stats->spans.begin(st);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT>), dim3(ntiles), dim3(kBlock), 0, st, ki,
-                         identity_vals ? static_cast<const uint32_t *>(nullptr) : vi, ko, vo, n, b, mask, table);
+      const uint32_t *vsrc = identity_vals ? static_cast<const uint32_t *>(nullptr) : vi;
+      if (small) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kSmallItems>), dim3(ntiles),
+                           dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table);
+      } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems>), dim3(ntiles),
+                           dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table);
+      }
       identity_vals = false;
       WP_LAUNCH_CHECK();
       if (stats) {
