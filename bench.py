@@ -209,6 +209,16 @@ def main():
                          "algorithmic_bytes_per_launch": int(avg_launch_bytes)},
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
         }
+        # the whole SA/LCP stage against the HBM peak (DESIGN.md section 4 lists the per-kernel bytes):
+        # round-0 sort (32 B per element and pass: 8 histogram + 24 scatter, - 4 for the identity pass),
+        # round-0 split 35, rank store 32, rounds >= 1 per active entry: LDS sort 28 + split 50 + rank store 32
+        n_sym, act = st["n_total"], st["active_per_round"]
+        sa_bytes = 32 * (radix_elems / max(args.steps, 1)) - 4 * n_sym + (35 + 32) * n_sym + 110 * sum(act[1:])
+        sa_ms = stage_ms.get("ms_sa", 0.0) / max(args.steps, 1)
+        if sa_ms > 0:
+            out["sa_lcp_stage"] = {"algorithmic_bytes": int(sa_bytes), "ms": round(sa_ms, 3),
+                                   "achieved": round(sa_bytes / 1e9 / (sa_ms / 1e3), 1), "unit": "GB/s",
+                                   "frac": round(sa_bytes / 1e9 / (sa_ms / 1e3) / HBM_PEAK_GBPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_ids = _cpu_baseline(text, vocab, int(args.cpu_sample_mb * 1e6))
             out["cpu_baseline"] = cb
