@@ -93,7 +93,10 @@ def main():
     dev = torch.device("cuda", dev_index)
     cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective tensors live
     dist = None
-    if world > 1:
+    # WP_BENCH_FORCE_GATHER=1: run the collective path with a single rank too (checks the RCCL calls on a
+    # one-GPU box; launch through torch.distributed.run --nproc-per-node 1)
+    distributed = world > 1 or os.environ.get("WP_BENCH_FORCE_GATHER") == "1"
+    if distributed:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -125,27 +128,38 @@ def main():
     d_text[:nbytes] = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
 
-    gather_buf = None
+    # The only collective: token ids -> rank 0 (all_gather of the counts, gather of fixed-capacity
+    # buffers).  Buffers are sized once, on the first (warm-up) step; after that the loop never reads a
+    # device value on the host, so the gather of step i runs on RCCL's stream while the kernels of
+    # step i+1 run on the encoder's streams.
+    gs = {"cap": None}
 
     def step():
         d_ids, n_ids = vocab_h.encode_device(d_text.data_ptr(), nbytes)
-        if world > 1:
-            # the only collective: token ids -> rank 0 (counts first, then max-padded gather)
-            cnt = torch.tensor([n_ids], dtype=torch.int64, device=cdev)
-            counts = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
-            dist.all_gather(counts, cnt)
-            mx = int(torch.stack(counts).max().item())
-            send = torch.zeros(mx, dtype=torch.int32, device=cdev)
+        if distributed:
+            if gs["cap"] is None:
+                cnt = torch.tensor([n_ids], dtype=torch.int64, device=cdev)
+                counts = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+                dist.all_gather(counts, cnt)
+                cap = int(int(torch.stack(counts).max().item()) * 1.1) + 1024
+                gs.update(cap=cap, cnt=cnt, counts=counts,
+                          send=torch.zeros(cap, dtype=torch.int32, device=cdev),
+                          recv=[torch.empty(cap, dtype=torch.int32, device=cdev) for _ in range(world)]
+                          if rank == 0 else None)
+            if n_ids > gs["cap"]:
+                raise SystemExit("id count %d exceeds the gather capacity %d" % (n_ids, gs["cap"]))
+            gs["cnt"].fill_(n_ids)
             if n_ids:
-                send[:n_ids] = torch.as_tensor(_DevView(d_ids, n_ids), device=dev).to(cdev)
-            nonlocal gather_buf
-            if rank == 0:
-                gather_buf = [torch.empty(mx, dtype=torch.int32, device=cdev) for _ in range(world)]
-            dist.gather(send, gather_buf if rank == 0 else None, dst=0)
+                view = torch.as_tensor(_DevView(d_ids, n_ids), device=dev)
+                gs["send"][:n_ids].copy_(view if cdev is dev else view.to(cdev))
+            # the ids must be out of the handle's buffer before the next encode overwrites it
+            torch.cuda.current_stream().synchronize()
+            dist.all_gather(gs["counts"], gs["cnt"])
+            dist.gather(gs["send"], gs["recv"], dst=0)
         return n_ids
 
     def fence():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -169,7 +183,7 @@ def main():
     st = vocab_h.stats()
 
     t = torch.tensor([dt, float(nbytes)], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if distributed:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -201,7 +215,7 @@ def main():
                        "sorted_depth": st["sorted_depth"], "symbol_bits": st["symbol_bits"],
                        "symbols_per_key": st["symbols_per_key"], "active_per_round": st["active_per_round"],
                        "radix_launches_per_step": radix_launches // max(args.steps, 1),
-                       "id_gather": ("%s gather to rank 0" % ("rccl" if backend == "nccl" else backend)) if world > 1
+                       "id_gather": ("%s gather to rank 0" % ("rccl" if backend == "nccl" else backend)) if distributed
                        else "none (single GPU)"},
             "roofline": {"bound": "hbm", "kernel": "radix_scatter_kernel<uint64, 20> (full-size tiles; the round-0 suffix sort)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -227,7 +241,7 @@ def main():
             gpu_ids = torch.as_tensor(_DevView(d_ids, n), device=dev)[:len(cpu_ids)].cpu().numpy()
             out["config"]["ids_match_cpu_port_on_sample"] = bool(np.array_equal(gpu_ids, cpu_ids))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

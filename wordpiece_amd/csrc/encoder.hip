@@ -493,9 +493,11 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                          d_agg);
       hipLaunchKernelGGL(rerank_chunk_kernel, dim3(cdiv(tiles, kRrChunk)), dim3(kBlock), 0, st, d_agg, tiles,
                          d_chunk_agg);
+      hipLaunchKernelGGL(rerank_prefix_kernel, dim3(cdiv(tiles, kRrChunk)), dim3(kBlock), 0, st, d_agg, d_chunk_agg,
+                         tiles);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
                          vals, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), d_tdep,
-                         n, d_agg, d_chunk_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp,
+                         n, d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp,
                          slots, other_vals, AG, adep, d_ghead, d_gdepth, c->d_scalars + 4);
     }
     fork();
@@ -563,8 +565,10 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                          n_act, adep, d_rank, d_gdepth, n, dcode.first_len, dcode.uniform_bits, rule, d_tdep, d_agg);
       hipLaunchKernelGGL(rerank_chunk_kernel, dim3(cdiv(tiles, kRrChunk)), dim3(kBlock), 0, st, d_agg, tiles,
                          d_chunk_agg);
+      hipLaunchKernelGGL(rerank_prefix_kernel, dim3(cdiv(tiles, kRrChunk)), dim3(kBlock), 0, st, d_agg, d_chunk_agg,
+                         tiles);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
-                         svals, slots, adep, d_tdep, n_act, d_agg, d_chunk_agg, d_sym, n, dcode.first_len,
+                         svals, slots, adep, d_tdep, n_act, d_agg, d_sym, n, dcode.first_len,
                          dcode.uniform_bits, rule, d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead,
                          d_gdepth, c->d_scalars + 4);
     }

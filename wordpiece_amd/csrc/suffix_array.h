@@ -116,10 +116,9 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
 }
 
 // The apply pass needs, per tile, the exclusive prefix of the tile aggregates (sums of the two
-// counts, running max of last_flag).  Two levels instead of a single-workgroup scan: a small kernel
-// reduces chunks of kRrChunk tiles, and every apply workgroup reduces the chunks before its own plus
-// the tiles before it inside its chunk (<= 2 * 256 L2-resident loads per workgroup) — no serial
-// spine, no extra dependency between launches.
+// counts, running max of last_flag).  Two small multi-workgroup kernels instead of a single-workgroup
+// scan (0.23 ms for 48.9 k tiles): one reduces chunks of kRrChunk tiles, one turns the tile
+// aggregates into exclusive prefixes chunk by chunk.
 constexpr int kRrChunk = kBlock;
 
 __device__ __forceinline__ RerankAgg block_reduce_agg(RerankAgg a, uint32_t (*sm)[4]) {
@@ -154,11 +153,14 @@ __global__ __launch_bounds__(kBlock) void rerank_chunk_kernel(const RerankAgg *_
   if (threadIdx.x == 0) chunk_agg[blockIdx.x] = a;
 }
 
-// exclusive prefix of tile `tile` (all threads of the workgroup get it)
-__device__ __forceinline__ RerankAgg tile_prefix_agg(const RerankAgg *__restrict__ agg,
-                                                     const RerankAgg *__restrict__ chunk_agg, unsigned tile,
-                                                     uint32_t (*sm)[4]) {
-  const unsigned chunk = tile / kRrChunk, in_chunk = tile % kRrChunk;
+// agg[t] <- exclusive prefix of tile t: every workgroup reduces the chunks before its own (one per
+// thread and step) and scans the kRrChunk tile aggregates of its chunk
+__global__ __launch_bounds__(kBlock) void rerank_prefix_kernel(RerankAgg *__restrict__ agg,
+                                                               const RerankAgg *__restrict__ chunk_agg,
+                                                               unsigned tiles) {
+  __shared__ uint32_t sm[3][4];
+  __shared__ uint32_t wa[4], wh[4], wm[4];
+  const unsigned chunk = blockIdx.x;
   RerankAgg a = {0, 0, 0};
   for (unsigned c = threadIdx.x; c < chunk; c += kBlock) {
     const RerankAgg v = chunk_agg[c];
@@ -166,13 +168,38 @@ __device__ __forceinline__ RerankAgg tile_prefix_agg(const RerankAgg *__restrict
     a.n_heads += v.n_heads;
     a.last_flag = max(a.last_flag, v.last_flag);
   }
-  if (threadIdx.x < in_chunk) {
-    const RerankAgg v = agg[chunk * kRrChunk + threadIdx.x];
-    a.n_active += v.n_active;
-    a.n_heads += v.n_heads;
-    a.last_flag = max(a.last_flag, v.last_flag);
+  const RerankAgg before = block_reduce_agg(a, sm);
+  const unsigned t = chunk * kRrChunk + threadIdx.x;
+  RerankAgg mine = {0, 0, 0};
+  if (t < tiles) mine = agg[t];
+  const int lane = lane_id(), w = wave_id();
+  uint32_t ia = mine.n_active, ih = mine.n_heads, im = mine.last_flag;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const uint32_t ta = __shfl_up(ia, d, kWave), th = __shfl_up(ih, d, kWave), tm = __shfl_up(im, d, kWave);
+    if (lane >= d) {
+      ia += ta;
+      ih += th;
+      im = max(im, tm);
+    }
   }
-  return block_reduce_agg(a, sm);
+  if (lane == kWave - 1) {
+    wa[w] = ia;
+    wh[w] = ih;
+    wm[w] = im;
+  }
+  __syncthreads();
+  RerankAgg o = before;
+  for (int q = 0; q < w; q++) {
+    o.n_active += wa[q];
+    o.n_heads += wh[q];
+    o.last_flag = max(o.last_flag, wm[q]);
+  }
+  const uint32_t pm = __shfl_up(im, 1, kWave);
+  o.n_active += ia - mine.n_active;
+  o.n_heads += ih - mine.n_heads;
+  if (lane > 0) o.last_flag = max(o.last_flag, pm);
+  if (t < tiles) agg[t] = o;
 }
 
 // number of equal symbols at a+t, b+t for t < maxlen (positions >= n never match)
@@ -395,13 +422,12 @@ template <typename SymT, bool ROUND0>
 __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ slots,
     const uint32_t *__restrict__ adep, const uint32_t *__restrict__ tdep, size_t m,
-    const RerankAgg *__restrict__ agg, const RerankAgg *__restrict__ chunk_agg, const SymT *__restrict__ sym, size_t n,
+    const RerankAgg *__restrict__ agg, const SymT *__restrict__ sym, size_t n,
     const uint8_t *__restrict__ first_len, int uniform_bits, DepthRule rule, uint32_t *__restrict__ sa,
     RankEntry *__restrict__ hd, int32_t *__restrict__ lcp, uint32_t *__restrict__ nslots,
     uint32_t *__restrict__ nvals, uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep,
     uint32_t *__restrict__ ghead, uint32_t *__restrict__ gdepth, uint32_t *__restrict__ totals) {
   __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
-  __shared__ uint32_t s_red[3][4];
   __shared__ uint8_t s_fl[kDecodeTableBytes];
   if (ROUND0 && !uniform_bits) {
     for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
@@ -418,7 +444,8 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     s_nh[w] = T.nh;
     s_last[w] = T.last;
   }
-  const RerankAgg pre = tile_prefix_agg(agg, chunk_agg, blockIdx.x, s_red);  // (has the barriers for s_na.. too)
+  const RerankAgg pre = agg[blockIdx.x];  // exclusive prefix (rerank_prefix_kernel)
+  __syncthreads();
   if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {  // the last tile knows the totals of the round
     const uint32_t ta = pre.n_active + s_na[0] + s_na[1] + s_na[2] + s_na[3];
     const uint32_t th = pre.n_heads + s_nh[0] + s_nh[1] + s_nh[2] + s_nh[3];
