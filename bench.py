@@ -132,30 +132,18 @@ def main():
     # buffers).  Buffers are sized once, on the first (warm-up) step; after that the loop never reads a
     # device value on the host, so the gather of step i runs on RCCL's stream while the kernels of
     # step i+1 run on the encoder's streams.
-    gs = {"cap": None}
+    gather = None
+    if distributed:
+        from wordpiece_amd.gather import IdGather
+        gather = IdGather(dist, rank, world, cdev)
 
     def step():
         d_ids, n_ids = vocab_h.encode_device(d_text.data_ptr(), nbytes)
         if distributed:
-            if gs["cap"] is None:
-                cnt = torch.tensor([n_ids], dtype=torch.int64, device=cdev)
-                counts = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
-                dist.all_gather(counts, cnt)
-                cap = int(int(torch.stack(counts).max().item()) * 1.1) + 1024
-                gs.update(cap=cap, cnt=cnt, counts=counts,
-                          send=torch.zeros(cap, dtype=torch.int32, device=cdev),
-                          recv=[torch.empty(cap, dtype=torch.int32, device=cdev) for _ in range(world)]
-                          if rank == 0 else None)
-            if n_ids > gs["cap"]:
-                raise SystemExit("id count %d exceeds the gather capacity %d" % (n_ids, gs["cap"]))
-            gs["cnt"].fill_(n_ids)
-            if n_ids:
-                view = torch.as_tensor(_DevView(d_ids, n_ids), device=dev)
-                gs["send"][:n_ids].copy_(view if cdev is dev else view.to(cdev))
+            view = (torch.as_tensor(_DevView(d_ids, n_ids), device=dev) if n_ids
+                    else torch.zeros(0, dtype=torch.int32, device=dev))
             # the ids must be out of the handle's buffer before the next encode overwrites it
-            torch.cuda.current_stream().synchronize()
-            dist.all_gather(gs["counts"], gs["cnt"])
-            dist.gather(gs["send"], gs["recv"], dst=0)
+            gather.step(view, n_ids, before_collective=torch.cuda.current_stream().synchronize)
         return n_ids
 
     def fence():

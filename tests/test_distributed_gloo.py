@@ -17,18 +17,13 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 
 def gather_ids(ids, rank, world, device="cpu"):
-    """The collective of bench.py: all_gather of counts, then a max-padded gather to rank 0."""
-    cnt = torch.tensor([len(ids)], dtype=torch.int64, device=device)
-    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(counts, cnt)
-    mx = int(torch.stack(counts).max().item())
-    send = torch.zeros(mx, dtype=torch.int32, device=device)
-    send[:len(ids)] = torch.as_tensor(ids, dtype=torch.int32)
-    bufs = [torch.empty(mx, dtype=torch.int32, device=device) for _ in range(world)] if rank == 0 else None
-    dist.gather(send, bufs, dst=0)
-    if rank != 0:
-        return None
-    return np.concatenate([bufs[r][:int(counts[r].item())].numpy() for r in range(world)])
+    """The collective of bench.py (wordpiece_amd/gather.py), two steps to cover the buffer reuse."""
+    from wordpiece_amd.gather import IdGather
+    g = IdGather(dist, rank, world, torch.device(device))
+    t = torch.as_tensor(np.ascontiguousarray(ids), dtype=torch.int32)
+    g.step(t, len(ids))
+    g.step(t, len(ids))
+    return g.result()
 
 
 def _worker(rank, world, port, text, vocab, out_path):
