@@ -82,3 +82,37 @@ def test_encode_external_batches(corpus):
         pos += batch
         size -= batch
     assert open(out).read() == "".join("%d " % i for i in exp)
+
+
+def test_encode_external_id_text_all_widths(tmp_path):
+    """The id text is written by a device kernel (format.h): ids of 1..6 digits and -1 (no [UNK] in
+    the vocab), several batches, compared with the reference's `fout << id << ' '` format."""
+    rng = np.random.default_rng(3)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+
+    def word(k):  # distinct lowercase words, 4..5 letters
+        s = ""
+        for _ in range(5):
+            s += letters[k % 26]
+            k //= 26
+        return s
+
+    vocab = [word(k) for k in range(120_000)]           # ids 0..119999: one to six digits
+    pick = np.concatenate([rng.integers(0, 10, 500), rng.integers(10, 1000, 2000),
+                           rng.integers(1000, 120_000, 60_000)])
+    rng.shuffle(pick)
+    words = [vocab[i] for i in pick]
+    for k in range(0, len(words), 50):
+        words[k] = "zzzzzz"                              # not in the vocab: -1
+    text = " ".join(words).encode()
+    tf, vf, out = tmp_path / "t.txt", tmp_path / "v.txt", tmp_path / "ids.txt"
+    tf.write_bytes(text)
+    vf.write_bytes("\n".join(vocab).encode() + b"\n")
+    W.linear.encodeExternal(str(tf), str(vf), str(out), 20 * 100_000)
+    got = open(out).read()
+    ids = [int(x) for x in got.split(" ") if x]
+    assert got == "".join("%d " % i for i in ids)        # exact format
+    assert -1 in ids and max(ids) >= 100_000 and min(i for i in ids if i >= 0) < 10
+    # batches are cut at spaces here, so the concatenation equals the unbatched encode
+    assert ids == W.Vocab(vocab).encode(text).tolist()
+    assert ids == O.Vocab(vocab).encode(text).tolist()

@@ -13,11 +13,13 @@
 #include <chrono>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <memory>
 
 #include "../../include/wordpiece_amd.h"
 #include "code.h"
 #include "decode.h"
+#include "format.h"
 #include "local_sort.h"
 #include "radix_sort.h"
 #include "scanline.h"
@@ -86,7 +88,7 @@ struct Context {
   // vocab tables on the device
   uint32_t *d_stream = nullptr, *d_elig_start = nullptr, *d_elig_info = nullptr, *d_soft = nullptr;
   int32_t *d_elig_id = nullptr, *d_tok_len = nullptr;
-  DeviceBuffer text_buf, a_buf, b_buf;
+  DeviceBuffer text_buf, a_buf, b_buf, fmt_buf;  // fmt_buf: id text of encodeExternal
   uint32_t *d_used = nullptr, *d_lut = nullptr, *d_scan_tmp = nullptr;  // code point tables
   uint32_t *d_scalars = nullptr;                                         // 16 words of device scalars
   uint8_t *d_code = nullptr;     // symbol code tables: cw u16[256] | len u8[256] | bmask u16[4096]
@@ -138,6 +140,7 @@ static void destroy_context(Context *c) {
   c->text_buf.release();
   c->a_buf.release();
   c->b_buf.release();
+  c->fmt_buf.release();
   for (auto &e : c->ev) {
     if (e) (void)hipEventDestroy(e);
   }
@@ -908,6 +911,29 @@ int wp_linear_encode_file(const char *text_file, const char *vocab_file, int32_t
   return rc;
 }
 
+// Host side of encodeExternal (linear.cpp:343-374): same batch rule and file format as the reference.
+// Per batch: upload, encode, format the ids as text on the device (format.h), download into one of
+// two pinned buffers; a writer thread appends that buffer to the file while the next batch is on the
+// GPU.
+namespace {
+struct PinnedText {
+  char *p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) WP_HIP(hipHostFree(p));
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 8 + (1 << 20);
+    WP_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), want));
+    cap = want;
+  }
+  ~PinnedText() {
+    if (p) (void)hipHostFree(p);
+  }
+};
+}  // namespace
+
 int wp_linear_encode_external(const char *text_file, const char *vocab_file, const char *out_file,
                               size_t memory_limit) {
   wp_vocab *v = nullptr;
@@ -920,8 +946,23 @@ int wp_linear_encode_external(const char *text_file, const char *vocab_file, con
     MappedFile mm(text_file);
     const char *begin = mm.data;
     size_t size = mm.size;
-    std::ofstream fout(out_file);
-    std::string chunk;
+    FILE *fout = std::fopen(out_file, "wb");
+    if (!fout) throw std::ios_base::failure(std::string("cannot open ") + out_file);
+    struct Closer {
+      FILE *f;
+      ~Closer() { std::fclose(f); }
+    } closer{fout};
+    PinnedText host_text[2];
+    std::future<void> pending[2];
+    struct Drain {  // a failing batch must not leave a writer thread behind
+      std::future<void> *p;
+      ~Drain() {
+        for (int i = 0; i < 2; i++) {
+          if (p[i].valid()) p[i].wait();
+        }
+      }
+    } drain{pending};
+    size_t batch_no = 0;
     while (size > 0) {
       size_t batch;
       if (size > max_batch) {  // linear.cpp:357-362: grow until the batch's last byte starts a space
@@ -935,18 +976,61 @@ int wp_linear_encode_external(const char *text_file, const char *vocab_file, con
       } else {
         batch = size;
       }
-      int32_t *ids = nullptr;
+      Context *c = get_context(v);
+      hipStream_t st = c->stream;
+      c->text_buf.ensure(batch + 64);
+      WP_HIP(hipMemsetAsync(static_cast<char *>(c->text_buf.p) + (batch & ~static_cast<size_t>(15)), 0, 32, st));
+      WP_HIP(hipMemcpyAsync(c->text_buf.p, begin, batch, hipMemcpyHostToDevice, st));
       size_t n = 0;
-      if (wp_linear_encode(v, begin, batch, &ids, &n) != WP_OK) throw std::runtime_error(g_last_error);
-      chunk.clear();
-      for (size_t i = 0; i < n; i++) {  // utils.cpp:30-35 format: "<id> "
-        chunk += std::to_string(ids[i]);
-        chunk += ' ';
+      encode_on_device(v, static_cast<const uint8_t *>(c->text_buf.p), batch, &n);
+      if (n > 0) {
+        // utils.cpp:30-35 format ("<id> " per id) on the device: byte counts, 64-bit offsets, text
+        const size_t tiles = cdiv(n, kFmtTile);
+        const size_t head = (tiles * (sizeof(uint32_t) + sizeof(unsigned long long)) + 8 + 255) & ~static_cast<size_t>(255);
+        c->fmt_buf.ensure(head + n * 7);  // typical: <= 6 digits + space; grown below if the ids are longer
+        auto layout = [&](uint32_t *&tb, unsigned long long *&to, unsigned long long *&total, char *&text) {
+          char *base = static_cast<char *>(c->fmt_buf.p);
+          to = reinterpret_cast<unsigned long long *>(base);
+          total = to + tiles;
+          tb = reinterpret_cast<uint32_t *>(total + 1);
+          text = base + head;
+        };
+        uint32_t *tb;
+        unsigned long long *to, *total;
+        char *d_out;
+        layout(tb, to, total, d_out);
+        hipLaunchKernelGGL(fmt_count_kernel, dim3(tiles), dim3(kBlock), 0, st, c->d_ids, n, tb);
+        hipLaunchKernelGGL(fmt_offsets_kernel, dim3(1), dim3(1024), 0, st, tb, tiles, to, total);
+        WP_LAUNCH_CHECK();
+        unsigned long long nbytes_out = 0;
+        WP_HIP(hipMemcpyAsync(&nbytes_out, total, sizeof(nbytes_out), hipMemcpyDeviceToHost, st));
+        WP_HIP(hipStreamSynchronize(st));
+        if (head + nbytes_out > c->fmt_buf.cap) {  // longer ids than assumed: regrow and redo the (cheap) counts
+          c->fmt_buf.ensure(head + nbytes_out);
+          layout(tb, to, total, d_out);
+          hipLaunchKernelGGL(fmt_count_kernel, dim3(tiles), dim3(kBlock), 0, st, c->d_ids, n, tb);
+          hipLaunchKernelGGL(fmt_offsets_kernel, dim3(1), dim3(1024), 0, st, tb, tiles, to, total);
+        }
+        hipLaunchKernelGGL(fmt_write_kernel, dim3(tiles), dim3(kBlock), 0, st, c->d_ids, n, to, d_out);
+        WP_LAUNCH_CHECK();
+        const int slot = static_cast<int>(batch_no & 1);
+        if (pending[slot].valid()) pending[slot].get();  // the writer of batch_no - 2 is done with this buffer
+        host_text[slot].ensure(nbytes_out);
+        WP_HIP(hipMemcpyAsync(host_text[slot].p, d_out, nbytes_out, hipMemcpyDeviceToHost, st));
+        WP_HIP(hipStreamSynchronize(st));
+        if (batch_no > 0 && pending[slot ^ 1].valid()) pending[slot ^ 1].get();  // keep the file in batch order
+        const char *src = host_text[slot].p;
+        const size_t cnt = static_cast<size_t>(nbytes_out);
+        pending[slot] = std::async(std::launch::async, [fout, src, cnt] {
+          if (std::fwrite(src, 1, cnt, fout) != cnt) throw std::ios_base::failure("short write to the id file");
+        });
+        batch_no++;
       }
-      fout.write(chunk.data(), static_cast<std::streamsize>(chunk.size()));
-      std::free(ids);
       begin += batch;
       size -= batch;
+    }
+    for (int i = 0; i < 2; i++) {
+      if (pending[i].valid()) pending[i].get();
     }
   });
 }
