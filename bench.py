@@ -31,11 +31,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/
 RADIX_BYTES_PER_ELEM = 24  # one radix pass reads and writes a 12-byte (key, index) record
 
 
-class _DevView:
-    """Zero-copy torch view of a device buffer owned by the library."""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+_DevView = W.DeviceIds  # zero-copy torch view of a device buffer owned by the library
 
 
 def _cpu_baseline(text, vocab, target_bytes):

@@ -2,6 +2,9 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  (before libwordpiece_amd.so: torch brings its own HIP runtime, and whichever
+#               copy of libamdhip64 is loaded first serves the whole process — torch sees no GPU behind
+#               the system copy; encode_tensor and bench.py need torch's GPU view)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

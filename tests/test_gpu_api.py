@@ -116,3 +116,17 @@ def test_encode_external_id_text_all_widths(tmp_path):
     # batches are cut at spaces here, so the concatenation equals the unbatched encode
     assert ids == W.Vocab(vocab).encode(text).tolist()
     assert ids == O.Vocab(vocab).encode(text).tolist()
+
+
+def test_encode_tensor_on_device(corpus):
+    """Text and ids stay in HBM (wp_linear_encode_device behind a torch tensor view)."""
+    import torch
+    _, _, text, vocab, _ = corpus
+    gv = W.Vocab(vocab)
+    exp = O.Vocab(vocab).encode(text[:500_003])
+    t = torch.frombuffer(bytearray(text[:500_003]), dtype=torch.uint8).cuda()  # odd length: staged and padded
+    ids = gv.encode_tensor(t)
+    assert ids.is_cuda and ids.dtype == torch.int32 and np.array_equal(ids.cpu().numpy(), exp)
+    view = gv.encode_tensor(t, copy=False)
+    assert np.array_equal(view.cpu().numpy(), exp)
+    assert gv.encode_tensor(torch.zeros(0, dtype=torch.uint8, device="cuda")).numel() == 0

@@ -160,6 +160,28 @@ class Vocab:
         _check(lib().wp_linear_encode_device(self._h, C.c_void_p(d_ptr), nbytes, C.byref(d_ids), C.byref(n)))
         return d_ids.value, n.value
 
+    def encode_tensor(self, text, copy=True):
+        """On-device consumer path: `text` is a uint8 torch tensor on the GPU of this
+        handle; returns the ids as an int32 torch tensor on the same device.  copy=False returns a
+        zero-copy view of the library's buffer, valid until the next call on this handle.
+        (Import torch before the first call into this package: both load a HIP runtime, and torch only
+        sees the GPU through its own copy.)"""
+        import torch
+        if text.dtype != torch.uint8 or not text.is_cuda or not text.is_contiguous():
+            raise WordPieceError("encode_tensor needs a contiguous uint8 CUDA/HIP tensor")
+        nbytes = text.numel()
+        if text.data_ptr() % 4 != 0 or nbytes % 4 != 0:
+            # the device entry point reads whole 4-byte words: pad into an aligned staging tensor
+            padded = torch.zeros((nbytes + 19) // 16 * 16, dtype=torch.uint8, device=text.device)
+            padded[:nbytes] = text
+            text = padded
+        torch.cuda.current_stream(text.device).synchronize()  # the library runs on its own HIP streams
+        d_ids, n = self.encode_device(text.data_ptr(), nbytes)
+        if n == 0:
+            return torch.zeros(0, dtype=torch.int32, device=text.device)
+        view = torch.as_tensor(DeviceIds(d_ids, n), device=text.device)
+        return view.clone() if copy else view
+
     def debug_fetch(self, which, capacity):
         out = np.zeros(max(capacity, 1), dtype=np.int32)
         n = C.c_size_t()
@@ -176,6 +198,14 @@ def _adopt_ids(ids, n):
     out = np.ctypeslib.as_array(ids, shape=(n,))
     weakref.finalize(out.base if out.base is not None else out, lib().wp_free, ids)  # the bottom of the view chain
     return out
+
+
+class DeviceIds:
+    """`__cuda_array_interface__` view of an id buffer in HBM owned by the library (torch.as_tensor,
+    cupy.asarray, numba … accept it without a copy)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
 
 class _Linear:
