@@ -1,6 +1,7 @@
 """Full-size runs of BASELINE.json's configs on one MI355X with size-independent checks.
 
-usage (on the GPU box):  python profiles/fullsize_check.py <english|multilingual|deep> <bytes> [out.json]
+usage (on the GPU box):  python tests/fullsize_check.py <english|multilingual|deep> <bytes> [out.json]
+(not collected by pytest: minutes of corpus generation; results are kept under profiles/)
 
 The corpus is generated in ~100 MB chunks by worker processes (before the GPU is touched), the
 vocabulary comes from chunk 0.  Checks:
@@ -18,7 +19,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from wordpiece_amd import synth  # noqa: E402
 
 
