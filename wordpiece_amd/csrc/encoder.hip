@@ -318,7 +318,8 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
            *d_emit_tmp = nullptr;
   int32_t *d_lcp = nullptr, *d_mid = nullptr, *d_rf = nullptr, *d_rb = nullptr;
   RerankAgg *d_agg = nullptr, *d_chunk_agg = nullptr;
-  uint32_t *d_ghead = nullptr, *d_large_id = nullptr, *d_large_off = nullptr, *d_gscan_tmp = nullptr, *LV0 = nullptr,
+  uint32_t *d_ghead = nullptr, *d_large_id = nullptr, *d_large_off = nullptr, *d_gscan_tmp = nullptr, *d_lg_head = nullptr,
+           *d_lg_off = nullptr, *LV0 = nullptr,
            *LV1 = nullptr, *LPOS = nullptr;
   uint64_t *LK1 = nullptr;
   int32_t *d_cover_f = nullptr, *d_cover_b = nullptr;
@@ -347,6 +348,8 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     d_large_id = ar.take<uint32_t>(n / 2 + 4);
     d_large_off = ar.take<uint32_t>(n / 2 + 4);
     d_gscan_tmp = ar.take<uint32_t>(cdiv(n / 2 + 4, kScanTile) + 8);
+    d_lg_head = ar.take<uint32_t>(n / kLsMaxGroup + 4);
+    d_lg_off = ar.take<uint32_t>(n / kLsMaxGroup + 4);
     LK1 = ar.take<uint64_t>(n);
     LV0 = ar.take<uint32_t>(n);
     LV1 = ar.take<uint32_t>(n);
@@ -431,6 +434,9 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                        c->d_scalars + 5, d_large_id, d_large_off, cap);
     device_exclusive_scan(d_large_id, d_large_id, cap, d_gscan_tmp, c->d_scalars + 6, st2, c->d_scalars + 5);
     device_exclusive_scan(d_large_off, d_large_off, cap, d_gscan_tmp, c->d_scalars + 7, st2, c->d_scalars + 5);
+    hipLaunchKernelGGL(large_table_kernel, dim3(std::min<size_t>(cdiv(cap, kBlock), 4096)), dim3(kBlock), 0, st2,
+                       d_ghead, c->d_scalars + 5, d_large_id, d_large_off, c->d_scalars + 6, c->d_scalars + 7,
+                       d_lg_head, d_lg_off);
     return true;
   };
   // rank[dst[k]] = val[k].  Random 4-byte stores leave the L2s as partial lines; one radix pass over
@@ -541,14 +547,13 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                        d_ghead, static_cast<uint32_t>(n_groups), d_rank, n, rb, skeys, svals);
     if (n_large > 0) {  // large groups (side stream, disjoint list positions): extract, global radix sort on
                         // (dense large id, second key), write back
-      hipLaunchKernelGGL(large_extract_kernel, dim3(std::min<size_t>(cdiv(n_act, kBlock), 8192)), dim3(kBlock), 0, st2, avals, AG, adep,
-                         n_act, d_ghead, d_large_id, d_large_off, d_rank, n, K1, LV0, LPOS);
       const int lgb = bit_length(n_large_groups > 0 ? n_large_groups - 1 : 0);
-      const BitRange ranges[2] = {{0, rb}, {32, 32 + lgb}};
-      const int lc = radix_sort_ranges<uint64_t>(K1, LV0, LK1, LV1, n_large, ranges, lgb > 0 ? 2 : 1, d_radix_tmp, st2,
-                                                 &c->rstats);
-      hipLaunchKernelGGL(large_writeback_kernel, dim3(cdiv(n_large, kBlock)), dim3(kBlock), 0, st2, lc ? LK1 : K1,
-                         lc ? LV1 : LV0, LPOS, n_large, AG, skeys, svals);
+      hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(cdiv(n_large, kLxSpan), kBlock / kWave)), dim3(kBlock), 0, st2,
+                         avals, adep, d_lg_head, d_lg_off, static_cast<uint32_t>(n_large_groups), n_large, d_rank, n, rb,
+                         K1, LV0, LPOS);
+      const int lc = radix_sort_pairs<uint64_t>(K1, LV0, LK1, LV1, n_large, 0, rb + lgb, d_radix_tmp, st2, &c->rstats);
+      hipLaunchKernelGGL(large_writeback_kernel, dim3(std::min<size_t>(cdiv(n_large, kBlock), 8192)), dim3(kBlock), 0,
+                         st2, lc ? LK1 : K1, lc ? LV1 : LV0, LPOS, n_large, AG, rb, skeys, svals);
       join();
     }
     const unsigned tiles = cdiv(n_act, kRrTile);

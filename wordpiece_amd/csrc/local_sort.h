@@ -65,39 +65,78 @@ __global__ __launch_bounds__(kBlock) void group_stats_kernel(const uint32_t *__r
   atomicAdd(&out[9 + c], 1ull);
 }
 
-// entries of large groups -> (key, val, list position) in the large list
+// Dense table of the large groups (after the two scans of group_classify's arrays):
+// lg_head[i] = list position of the i-th large group, lg_off[i] = its offset in the large list,
+// lg_off[n_large_groups] = n_large.
+__global__ __launch_bounds__(kBlock) void large_table_kernel(const uint32_t *__restrict__ ghead,
+                                                             const uint32_t *__restrict__ n_groups_dev,
+                                                             const uint32_t *__restrict__ large_id,
+                                                             const uint32_t *__restrict__ large_off,
+                                                             const uint32_t *__restrict__ n_large_groups_dev,
+                                                             const uint32_t *__restrict__ n_large_dev,
+                                                             uint32_t *__restrict__ lg_head,
+                                                             uint32_t *__restrict__ lg_off) {
+  const size_t ng = *n_groups_dev;
+  for (size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; g < ng;
+       g += static_cast<size_t>(gridDim.x) * kBlock) {
+    const uint32_t h = ghead[g];
+    if (ghead[g + 1] - h > kLsMaxGroup) {
+      const uint32_t i = large_id[g];
+      lg_head[i] = h;
+      lg_off[i] = large_off[g];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) lg_off[*n_large_groups_dev] = *n_large_dev;
+}
+
+// entries of large groups -> (key, val, list position) in the large list; key = dense large-group
+// number << rbits | second key.  A wave owns kLxSpan consecutive positions of the large list: one
+// search for its first group, then it only moves forward (large groups are long runs).
+constexpr int kLxSpan = 2048;
 __global__ __launch_bounds__(kBlock) void large_extract_kernel(
-    const uint32_t *__restrict__ aval, const uint32_t *__restrict__ agid, const uint32_t *__restrict__ adep,
-    size_t m, const uint32_t *__restrict__ ghead, const uint32_t *__restrict__ large_id,
-    const uint32_t *__restrict__ large_off, const RankEntry *__restrict__ rank, size_t n,
-    uint64_t *__restrict__ lkey, uint32_t *__restrict__ lval, uint32_t *__restrict__ lpos) {
-  for (size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; k < m;
-       k += static_cast<size_t>(gridDim.x) * kBlock) {
-    const uint32_t g = agid[k];
-    const uint32_t h0 = ghead[g];
-    if (ghead[g + 1] - h0 <= kLsMaxGroup) continue;
-    const uint32_t j = large_off[g] + (static_cast<uint32_t>(k) - h0);
+    const uint32_t *__restrict__ aval, const uint32_t *__restrict__ adep, const uint32_t *__restrict__ lg_head,
+    const uint32_t *__restrict__ lg_off, uint32_t n_lg, size_t n_large, const RankEntry *__restrict__ rank, size_t n,
+    int rbits, uint64_t *__restrict__ lkey, uint32_t *__restrict__ lval, uint32_t *__restrict__ lpos) {
+  const int lane = lane_id();
+  const size_t wave = static_cast<size_t>(blockIdx.x) * (kBlock / kWave) + wave_id();
+  const size_t j0 = wave * kLxSpan;
+  if (j0 >= n_large) return;
+  // last group with lg_off[i] <= j0
+  uint32_t lo = 0, hi = n_lg;
+  while (hi - lo > 1) {
+    const uint32_t md = (lo + hi) >> 1;
+    if (lg_off[md] <= j0) lo = md; else hi = md;
+  }
+  uint32_t i = lo;
+  const size_t j1 = min(n_large, j0 + kLxSpan);
+  for (size_t j = j0 + lane; j < j1; j += kWave) {
+    while (j >= lg_off[i + 1]) i++;
+    const uint32_t k = lg_head[i] + static_cast<uint32_t>(j - lg_off[i]);
     const uint32_t v = aval[k];
     const size_t t = static_cast<size_t>(v) + adep[k];
     const uint32_t r2 = t < n ? rank_of(rank[t]) + 1u : 0u;
-    lkey[j] = (static_cast<uint64_t>(large_id[g]) << 32) | r2;
+    lkey[j] = (static_cast<uint64_t>(i) << rbits) | r2;
     lval[j] = v;
-    lpos[j] = static_cast<uint32_t>(k);
+    lpos[j] = k;
   }
 }
 
-// sorted large list -> back to the list positions, with the original group id in the high word
+// sorted large list -> back to the list positions (lpos[j]: the list position behind large-list
+// position j; the sort keeps every group's entries inside the group's range), with the original group
+// id in the high word again
 __global__ __launch_bounds__(kBlock) void large_writeback_kernel(const uint64_t *__restrict__ lkey,
                                                                  const uint32_t *__restrict__ lval,
                                                                  const uint32_t *__restrict__ lpos, size_t nl,
-                                                                 const uint32_t *__restrict__ agid,
+                                                                 const uint32_t *__restrict__ agid, int rbits,
                                                                  uint64_t *__restrict__ kout,
                                                                  uint32_t *__restrict__ vout) {
-  const size_t j = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (j >= nl) return;
-  const uint32_t k = lpos[j];
-  kout[k] = (static_cast<uint64_t>(agid[k]) << 32) | (lkey[j] & 0xffffffffull);
-  vout[k] = lval[j];
+  const uint64_t rmask = (1ull << rbits) - 1ull;
+  for (size_t j = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; j < nl;
+       j += static_cast<size_t>(gridDim.x) * kBlock) {
+    const uint32_t k = lpos[j];
+    kout[k] = (static_cast<uint64_t>(agid[k]) << 32) | (lkey[j] & rmask);
+    vout[k] = lval[j];
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void local_sort_kernel(const uint32_t *__restrict__ aval,
