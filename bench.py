@@ -112,7 +112,9 @@ def main():
         text = data[s:e][:nbytes_target] if nbytes_target else data[s:e]
         workload = "local files %s / %s" % (args.text_file, args.vocab_file)
     else:
-        text, vocab = synth.english_corpus(nbytes_target, seed=args.seed + 1000 * rank, vocab_size=args.vocab_size)
+        # one lexicon and one (replicated) vocabulary for all ranks; rank r > 0 draws its own word sequence
+        text, vocab = synth.english_corpus(nbytes_target, seed=args.seed, vocab_size=args.vocab_size,
+                                           text_seed=rank if rank > 0 else None)
         workload = ("configs[1]: %.0f MB English-shaped synthetic shard per GPU (SURVEY 8d config 2), "
                     "%d-line BERT-like vocab" % (args.mb, len(vocab)))
     nbytes = len(text)

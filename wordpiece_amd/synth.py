@@ -59,14 +59,18 @@ def english_vocab(lex, rng, vocab_size=29000, n_top=18000):
     return vocab
 
 
-def english_corpus(n_bytes, seed=0, vocab_size=29000, lexicon_size=200000, chunk=32 << 20):
+def english_corpus(n_bytes, seed=0, vocab_size=29000, lexicon_size=200000, chunk=32 << 20, text_seed=None):
     """English-shaped ASCII text of ~n_bytes bytes (cut at a separator) + a BERT-like vocab.
 
     Zipf(s=1.05) words from a lexicon with Poisson(5.5) lengths; separators
-    {' ' x7, ', ', '. ', '\\n'}/10.  Returns (bytes, list[str])."""
+    {' ' x7, ', ', '. ', '\\n'}/10.  Returns (bytes, list[str]).
+    text_seed: draw the word sequence from a separate stream (same lexicon and vocab, different
+    text: the shards of a multi-GPU run)."""
     rng = np.random.default_rng(seed)
     lex = _lexicon(rng, lexicon_size)
     vocab = english_vocab(lex, rng, vocab_size)
+    if text_seed is not None:
+        rng = np.random.default_rng([seed, text_seed])
     seps = [b" "] * 7 + [b", ", b". ", b"\n"]
     table = lex + seps
     src = np.frombuffer(b"".join(table), dtype=np.uint8)
