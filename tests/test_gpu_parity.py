@@ -240,6 +240,29 @@ def test_soft_spacing_chars_switch_to_cover_anchors():
     assert gv3.stats()["anchor_mode"] == 0
 
 
+def test_single_word_text_random_split_300k():
+    """tests.cpp:259-272 shape: one long lowercase word cut into many tokens; positive (every piece
+    in the vocab) and negative (first piece missing: the whole word is one [UNK]-less -1)."""
+    for positive in (True, False):
+        s, vocab = synth.random_split_case(77, 300_000, 3000, positive)
+        gv = W.Vocab(vocab)
+        ids = gv.encode(s)
+        st = gv.stats()
+        assert st["anchor_mode"] == 1 and st["n_anchors"] == 1
+        exp = _oracle_ids_fast(s, vocab)
+        assert np.array_equal(ids, exp)
+        assert (len(ids) == 3000) if positive else (ids.tolist() == [-1])
+    # long words between ordinary ones: the [UNK] skip jumps over tiles without a word-prefix position
+    rng = np.random.default_rng(8)
+    words = []
+    for k in range(40):
+        words.append(rng.integers(97, 123, int(rng.integers(1, 30_000))).astype(np.uint8).tobytes())
+        words.append(b"ab" if k % 3 else b"zz,")
+    text = b" ".join(words)
+    vocab = ["ab", "##b", "a", ",", "zz"]
+    assert np.array_equal(W.Vocab(vocab).encode(text), O.Vocab(vocab).encode(text))
+
+
 def test_kasai_kernel_gives_same_lcp():
     text, vocab = synth.english_corpus(300_000, seed=8, vocab_size=3000)
     d = O.Vocab(vocab).encode_debug(text)

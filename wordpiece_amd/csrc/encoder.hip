@@ -462,9 +462,8 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   uint32_t *slots = AS0, *other_slots = AS1;
   uint32_t *adep = AD0, *other_dep = AD1;
   bool classified = false;
-  if (n_text > 0) {
-    // side stream: the anchor list and the cleared emit array only need the class bytes; they run
-    // next to the (gather/scatter bound) rerank kernels rather than next to the streaming radix passes
+  // side stream: the anchor list and the cleared emit array only need the class bytes
+  auto launch_anchors = [&] {
     fork();
     const unsigned atiles = cdiv(n_text, kAnchorTile);
     WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st2));
@@ -475,7 +474,12 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                        static_cast<const uint8_t *>(nullptr), n_text, d_anchor_cnt, d_anchors);
     hipLaunchKernelGGL(anchor_gap_kernel, dim3(std::min<size_t>(atiles, 1024)), dim3(kBlock), 0, st2, d_anchors,
                        c->d_scalars + 10, n_text, c->d_scalars + 11);
-  }
+  };
+  // They run next to the scanline stage (small latency-bound kernels) rather than next to the round-0
+  // split or the radix passes, which want the bandwidth themselves (14.03 -> 13.97 ms; WP_ANCHOR_LATE=0
+  // puts them back next to the split).
+  static const bool anchors_late = !(getenv("WP_ANCHOR_LATE") && atoi(getenv("WP_ANCHOR_LATE")) == 0);
+  if (n_text > 0 && !anchors_late) launch_anchors();
   // group split of a round: count / spine / apply kernels, or (WP_OPT_FUSED_RERANK, env WP_RERANK=fused)
   // one kernel with a chained scan across tiles
   static const bool env_fused = getenv("WP_RERANK") && std::strcmp(getenv("WP_RERANK"), "fused") == 0;
@@ -517,7 +521,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   }
   fetch_scalars(c, 12);
   size_t n_anchors = n_text > 0 ? c->h_scalars[10] : 0;  // (the side stream was joined above)
-  const size_t max_anchor_gap = n_text > 0 ? c->h_scalars[11] : 0;
+  size_t max_anchor_gap = n_text > 0 ? c->h_scalars[11] : 0;
   size_t n_act = c->h_scalars[4], n_groups = c->h_scalars[5];
   size_t n_large_groups = classified ? c->h_scalars[6] : 0, n_large = classified ? c->h_scalars[7] : 0;
   static const bool group_stats = getenv("WP_GROUP_STATS") && atoi(getenv("WP_GROUP_STATS")) != 0;
@@ -610,6 +614,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[4], st));
 
   // ---------------- who marks + scanlines ----------------
+  if (n_text > 0 && anchors_late) launch_anchors();
   StepTable steps{};
   MarkView mv{};
   {
@@ -658,8 +663,14 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   int32_t *d_ids = reinterpret_cast<int32_t *>(V1);
   size_t n_ids = 0;
   if (n_text > 0) {
-    WalkArgs wa{d_cls, n_text, d_rank, steps, c->d_tok_len, hv.unk_id, d_emit, nullptr};
+    WalkArgs wa{d_cls, n_text, d_rank, steps, c->d_tok_len, hv.unk_id, d_emit, nullptr, nullptr};
     S.anchor_mode = 0;
+    if (anchors_late) {
+      join();
+      fetch_scalars(c, 12);
+      n_anchors = c->h_scalars[10];
+      max_anchor_gap = c->h_scalars[11];
+    }
     if (v->cover_anchors || max_anchor_gap > kMaxAnchorGap) {
       // long stretches without class-rule anchors ("soft" spacing chars): anchors from the matches
       // themselves (walk.h).  The large-group buffers of the suffix sort are free by now.
@@ -668,8 +679,10 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       const unsigned rtiles = cdiv(n_text, kReachTile), atiles = cdiv(n_text, kAnchorTile);
       hipLaunchKernelGGL(reach_kernel, dim3(rtiles), dim3(kBlock), 0, st, wa, d_reach, d_reach_tiles);
       hipLaunchKernelGGL(reach_spine_kernel, dim3(1), dim3(1024), 0, st, d_reach_tiles, static_cast<size_t>(rtiles));
+      uint32_t *d_wp_tiles = d_reach_tiles + rtiles + 1;  // first word-prefix position at or behind each tile
       hipLaunchKernelGGL(cover_flags_kernel, dim3(rtiles), dim3(kBlock), 0, st, d_cls, d_reach, d_reach_tiles, n_text,
-                         d_aflags);
+                         d_aflags, d_wp_tiles);
+      hipLaunchKernelGGL(suffix_min_kernel, dim3(1), dim3(1024), 0, st, d_wp_tiles, static_cast<size_t>(rtiles));
       hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, d_aflags, n_text,
                          d_anchor_cnt);
       device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st);
@@ -679,6 +692,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       fetch_scalars(c, 11);
       n_anchors = c->h_scalars[10];
       wa.aflags = d_aflags;
+      wa.wp_from_tile = d_wp_tiles;
       S.anchor_mode = 1;
     }
     S.n_anchors = static_cast<int64_t>(n_anchors);

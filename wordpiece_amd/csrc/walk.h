@@ -15,6 +15,8 @@
 
 namespace wp {
 
+constexpr int kReachTile = kBlock * 8;  // tile of the coverage-rule kernels (a power of two)
+constexpr size_t kMaxAnchorGap = 2048;  // longer gaps between class-rule anchors switch the anchor rule
 constexpr int32_t kNoEmit = static_cast<int32_t>(0x80808080u);  // hipMemset(0x80) pattern; ids are >= -1
 
 struct WalkArgs {
@@ -26,6 +28,7 @@ struct WalkArgs {
   int32_t unk_id;
   int32_t *emit;
   const uint8_t *aflags;  // != nullptr: anchors are given per position (coverage-based anchors, below)
+  const uint32_t *wp_from_tile;  // with aflags: first word-prefix position >= t * kReachTile (n_text: none)
 };
 
 __device__ __forceinline__ bool w_space(const WalkArgs &a, size_t p) { return a.cls[p] & kClsSpace; }
@@ -62,7 +65,15 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
       }
       a.emit[p] = a.unk_id;
       ++p;
-      while (p < end && !w_word_prefix(a, p)) ++p;
+      while (p < end && !w_word_prefix(a, p)) {
+        ++p;
+        // coverage mode (texts with very long words): jump over whole tiles without a word-prefix
+        // position instead of stepping through them (a 10 M-char word otherwise costs a lane 2 s)
+        if (a.wp_from_tile && (p & (kReachTile - 1)) == 0 && p < end) {
+          p = min(static_cast<size_t>(a.wp_from_tile[p / kReachTile]), end);
+          break;
+        }
+      }
       since = p;
     }
     while (p < end && w_space(a, p)) ++p;
@@ -177,8 +188,6 @@ __global__ __launch_bounds__(kBlock) void anchor_gap_kernel(const uint32_t *__re
   if (threadIdx.x == 0 && m > 0) atomicMax(max_gap, static_cast<uint32_t>(m));
 }
 
-constexpr int kReachTile = kBlock * 8;
-constexpr size_t kMaxAnchorGap = 2048;  // longer gaps between class-rule anchors switch the anchor rule
 
 // reach[q] = q + length of the token the walk would take at q (q itself: none, or a space)
 __global__ __launch_bounds__(kBlock) void reach_kernel(WalkArgs a, uint32_t *__restrict__ reach,
@@ -231,8 +240,11 @@ __global__ __launch_bounds__(1024) void reach_spine_kernel(uint32_t *__restrict_
 __global__ __launch_bounds__(kBlock) void cover_flags_kernel(const uint8_t *__restrict__ cls,
                                                              const uint32_t *__restrict__ reach,
                                                              const uint32_t *__restrict__ tile_before, size_t n,
-                                                             uint8_t *__restrict__ aflags) {
+                                                             uint8_t *__restrict__ aflags,
+                                                             uint32_t *__restrict__ tile_first_wp) {
   __shared__ int32_t wm[4];
+  __shared__ int32_t sm_min[8];
+  int32_t first_wp = 0x7fffffff;  // first word-prefix position among this thread's
   const int lane = lane_id(), w = wave_id();
   const size_t p0 = static_cast<size_t>(blockIdx.x) * kReachTile + static_cast<size_t>(threadIdx.x) * 8;
   int32_t r[8], mx = 0;
@@ -256,7 +268,39 @@ __global__ __launch_bounds__(kBlock) void cover_flags_kernel(const uint8_t *__re
       const bool wp = p == 0 || (c & kClsSpacing) || (cls[p - 1] & kClsSpacing);
       aflags[p] = (!(c & kClsSpace) && wp && cover <= static_cast<int32_t>(p)) ? 1 : 0;
       cover = max(cover, r[j]);
+      if (wp) first_wp = min(first_wp, static_cast<int32_t>(p));
     }
+  }
+  const int32_t m = block_reduce_min(first_wp, sm_min);
+  if (threadIdx.x == 0) tile_first_wp[blockIdx.x] = m == 0x7fffffff ? static_cast<uint32_t>(n) : static_cast<uint32_t>(m);
+}
+
+// in place: t[i] <- min over tiles >= i (single workgroup, from the back)
+__global__ __launch_bounds__(1024) void suffix_min_kernel(uint32_t *__restrict__ t, size_t tiles) {
+  __shared__ uint32_t wm[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t carry = 0xffffffffu;
+  for (size_t done = 0; done < tiles; done += 1024) {
+    // this step covers indices [hi - 1024, hi) from the back; thread x owns index hi - 1 - x
+    const size_t hi = tiles - done;
+    const bool ok = threadIdx.x < hi;
+    const size_t i = ok ? hi - 1 - threadIdx.x : 0;
+    uint32_t v = ok ? t[i] : 0xffffffffu;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const uint32_t u = __shfl_up(v, d, kWave);
+      if (lane >= d) v = min(v, u);
+    }
+    if (lane == kWave - 1) wm[w] = v;
+    __syncthreads();
+    uint32_t before = carry, all = carry;
+    for (int q = 0; q < 16; q++) {
+      if (q < w) before = min(before, wm[q]);
+      all = min(all, wm[q]);
+    }
+    if (ok) t[i] = min(v, before);
+    carry = all;
+    __syncthreads();
   }
 }
 
