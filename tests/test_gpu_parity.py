@@ -263,6 +263,23 @@ def test_single_word_text_random_split_300k():
     assert np.array_equal(W.Vocab(vocab).encode(text), O.Vocab(vocab).encode(text))
 
 
+def test_long_whitespace_runs():
+    """Leading / inner / trailing whitespace runs far longer than a tile: no lane may step through them
+    (class rule: return at the first hard space; coverage rule: per-tile table of non-space positions)."""
+    en, vocab = synth.english_corpus(200_000, seed=19, vocab_size=3000)
+    text = b" " * 300_000 + en[:100_000] + b" \n\t" * 150_000 + en[100_000:] + b"\n" * 200_000
+    exp = _oracle_ids_fast(text, vocab)
+    gv = W.Vocab(vocab)
+    assert np.array_equal(gv.encode(text), exp) and gv.stats()["anchor_mode"] == 0
+    assert np.array_equal(_cover_ids(text, vocab), exp)          # coverage rule forced
+    assert W.Vocab(vocab).encode(b" " * 1_000_000).size == 0      # nothing but blanks
+    # a vocabulary with a soft space (a token that contains one, SURVEY Q13): stepping paths
+    vocab2 = vocab + ["of the", "##s of"]
+    text2 = b"  " * 5000 + en[:50_000] + b" " * 20_000 + en[50_000:100_000]
+    assert np.array_equal(W.Vocab(vocab2).encode(text2), O.Vocab(vocab2).encode(text2))
+    assert np.array_equal(_cover_ids(text2, vocab2), O.Vocab(vocab2).encode(text2))
+
+
 def test_kasai_kernel_gives_same_lcp():
     text, vocab = synth.english_corpus(300_000, seed=8, vocab_size=3000)
     d = O.Vocab(vocab).encode_debug(text)

@@ -353,7 +353,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     LK1 = ar.take<uint64_t>(n);
     LV0 = ar.take<uint32_t>(n);
     LV1 = ar.take<uint32_t>(n);
-    LPOS = ar.take<uint32_t>(n);
+    LPOS = ar.take<uint32_t>(n + 16);
     d_agg = ar.take<RerankAgg>(rr_tiles + 1);
     d_chunk_agg = ar.take<RerankAgg>(cdiv(rr_tiles, kRrChunk) + 1);
     d_mslot0 = ar.take<uint32_t>(M + 1);
@@ -473,7 +473,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     hipLaunchKernelGGL(anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls,
                        static_cast<const uint8_t *>(nullptr), n_text, d_anchor_cnt, d_anchors);
     hipLaunchKernelGGL(anchor_gap_kernel, dim3(std::min<size_t>(atiles, 1024)), dim3(kBlock), 0, st2, d_anchors,
-                       c->d_scalars + 10, n_text, c->d_scalars + 11);
+                       c->d_scalars + 10, n_text, d_cls, hv.soft.empty() ? 1 : 0, c->d_scalars + 11);
   };
   // They run next to the scanline stage (small latency-bound kernels) rather than next to the round-0
   // split or the radix passes, which want the bandwidth themselves (14.03 -> 13.97 ms; WP_ANCHOR_LATE=0
@@ -663,7 +663,8 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   int32_t *d_ids = reinterpret_cast<int32_t *>(V1);
   size_t n_ids = 0;
   if (n_text > 0) {
-    WalkArgs wa{d_cls, n_text, d_rank, steps, c->d_tok_len, hv.unk_id, d_emit, nullptr, nullptr};
+    WalkArgs wa{d_cls, n_text, d_rank, steps, c->d_tok_len, hv.unk_id, d_emit, nullptr, nullptr, nullptr,
+                hv.soft.empty() ? 1 : 0};
     S.anchor_mode = 0;
     if (anchors_late) {
       join();
@@ -680,9 +681,11 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       hipLaunchKernelGGL(reach_kernel, dim3(rtiles), dim3(kBlock), 0, st, wa, d_reach, d_reach_tiles);
       hipLaunchKernelGGL(reach_spine_kernel, dim3(1), dim3(1024), 0, st, d_reach_tiles, static_cast<size_t>(rtiles));
       uint32_t *d_wp_tiles = d_reach_tiles + rtiles + 1;  // first word-prefix position at or behind each tile
+      uint32_t *d_ns_tiles = d_wp_tiles + rtiles + 1;  // same for non-space positions
       hipLaunchKernelGGL(cover_flags_kernel, dim3(rtiles), dim3(kBlock), 0, st, d_cls, d_reach, d_reach_tiles, n_text,
-                         d_aflags, d_wp_tiles);
+                         d_aflags, d_wp_tiles, d_ns_tiles);
       hipLaunchKernelGGL(suffix_min_kernel, dim3(1), dim3(1024), 0, st, d_wp_tiles, static_cast<size_t>(rtiles));
+      hipLaunchKernelGGL(suffix_min_kernel, dim3(1), dim3(1024), 0, st, d_ns_tiles, static_cast<size_t>(rtiles));
       hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, d_aflags, n_text,
                          d_anchor_cnt);
       device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st);
@@ -693,6 +696,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       n_anchors = c->h_scalars[10];
       wa.aflags = d_aflags;
       wa.wp_from_tile = d_wp_tiles;
+      wa.ns_from_tile = d_ns_tiles;
       S.anchor_mode = 1;
     }
     S.n_anchors = static_cast<int64_t>(n_anchors);

@@ -29,6 +29,8 @@ struct WalkArgs {
   int32_t *emit;
   const uint8_t *aflags;  // != nullptr: anchors are given per position (coverage-based anchors, below)
   const uint32_t *wp_from_tile;  // with aflags: first word-prefix position >= t * kReachTile (n_text: none)
+  const uint32_t *ns_from_tile;  // with aflags: first non-space position >= t * kReachTile (n_text: none)
+  int all_hard;  // no spacing char occurs inside an eligible multi-char token (every sane vocabulary)
 };
 
 __device__ __forceinline__ bool w_space(const WalkArgs &a, size_t p) { return a.cls[p] & kClsSpace; }
@@ -76,7 +78,19 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
       }
       since = p;
     }
-    while (p < end && w_space(a, p)) ++p;
+    if (p < end && w_space(a, p)) {
+      // class rule with only hard spacing chars: the first position behind the spaces is an anchor of
+      // its own, whatever it is — no need to step through the run (a megabyte of blanks otherwise
+      // stalls this lane for 0.2 s)
+      if (!a.aflags && a.all_hard) return;
+      while (p < end && w_space(a, p)) {
+        ++p;
+        if (a.ns_from_tile && (p & (kReachTile - 1)) == 0 && p < end) {  // coverage mode: jump over blank tiles
+          p = min(static_cast<size_t>(a.ns_from_tile[p / kReachTile]), end);
+          break;
+        }
+      }
+    }
     if (p >= end || w_anchor(a, p)) return;
     // after skipped spaces p is a word-prefix position: counter restarts
     if (w_word_prefix(a, p)) since = p;
@@ -174,6 +188,7 @@ __global__ __launch_bounds__(kBlock) void anchor_write_kernel(const uint8_t *__r
 // what an anchor needs.  Cost: one match lookup per text position instead of one per visited one.
 __global__ __launch_bounds__(kBlock) void anchor_gap_kernel(const uint32_t *__restrict__ anchors,
                                                             const uint32_t *__restrict__ n_anchors_dev, size_t n_text,
+                                                            const uint8_t *__restrict__ cls, int all_hard,
                                                             uint32_t *__restrict__ max_gap) {
   __shared__ int32_t sm[8];
   const size_t na = *n_anchors_dev;
@@ -182,12 +197,21 @@ __global__ __launch_bounds__(kBlock) void anchor_gap_kernel(const uint32_t *__re
        k += static_cast<size_t>(gridDim.x) * kBlock) {
     const uint32_t hi = k < na ? anchors[k] : static_cast<uint32_t>(n_text);
     const uint32_t lo = k > 0 ? anchors[k - 1] : 0u;
-    g = max(g, hi - lo);
+    uint32_t d = hi - lo;
+    if (d > kMaxAnchorGap && all_hard) {
+      // with only hard spacing chars a lane stops at the first space (walk_from), so a long blank run
+      // behind a word is not a long walk: measure up to the first space (k == 0: leading blanks are
+      // nobody's walk)
+      uint32_t q = lo;
+      const uint32_t stop = min(hi, lo + static_cast<uint32_t>(kMaxAnchorGap) + 1u);
+      while (q < stop && !(cls[q] & kClsSpace)) q++;
+      d = q - lo;
+    }
+    g = max(g, d);
   }
   const int32_t m = -block_reduce_min(-static_cast<int32_t>(g), sm);
   if (threadIdx.x == 0 && m > 0) atomicMax(max_gap, static_cast<uint32_t>(m));
 }
-
 
 // reach[q] = q + length of the token the walk would take at q (q itself: none, or a space)
 __global__ __launch_bounds__(kBlock) void reach_kernel(WalkArgs a, uint32_t *__restrict__ reach,
@@ -241,10 +265,11 @@ __global__ __launch_bounds__(kBlock) void cover_flags_kernel(const uint8_t *__re
                                                              const uint32_t *__restrict__ reach,
                                                              const uint32_t *__restrict__ tile_before, size_t n,
                                                              uint8_t *__restrict__ aflags,
-                                                             uint32_t *__restrict__ tile_first_wp) {
+                                                             uint32_t *__restrict__ tile_first_wp,
+                                                             uint32_t *__restrict__ tile_first_ns) {
   __shared__ int32_t wm[4];
   __shared__ int32_t sm_min[8];
-  int32_t first_wp = 0x7fffffff;  // first word-prefix position among this thread's
+  int32_t first_wp = 0x7fffffff, first_ns = 0x7fffffff;  // first word-prefix / non-space position of this thread
   const int lane = lane_id(), w = wave_id();
   const size_t p0 = static_cast<size_t>(blockIdx.x) * kReachTile + static_cast<size_t>(threadIdx.x) * 8;
   int32_t r[8], mx = 0;
@@ -269,10 +294,15 @@ __global__ __launch_bounds__(kBlock) void cover_flags_kernel(const uint8_t *__re
       aflags[p] = (!(c & kClsSpace) && wp && cover <= static_cast<int32_t>(p)) ? 1 : 0;
       cover = max(cover, r[j]);
       if (wp) first_wp = min(first_wp, static_cast<int32_t>(p));
+      if (!(c & kClsSpace)) first_ns = min(first_ns, static_cast<int32_t>(p));
     }
   }
   const int32_t m = block_reduce_min(first_wp, sm_min);
-  if (threadIdx.x == 0) tile_first_wp[blockIdx.x] = m == 0x7fffffff ? static_cast<uint32_t>(n) : static_cast<uint32_t>(m);
+  const int32_t m2 = block_reduce_min(first_ns, sm_min);
+  if (threadIdx.x == 0) {
+    tile_first_wp[blockIdx.x] = m == 0x7fffffff ? static_cast<uint32_t>(n) : static_cast<uint32_t>(m);
+    tile_first_ns[blockIdx.x] = m2 == 0x7fffffff ? static_cast<uint32_t>(n) : static_cast<uint32_t>(m2);
+  }
 }
 
 // in place: t[i] <- min over tiles >= i (single workgroup, from the back)
@@ -307,9 +337,11 @@ __global__ __launch_bounds__(1024) void suffix_min_kernel(uint32_t *__restrict__
 __global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a, const uint32_t *__restrict__ anchors,
                                                       const uint32_t *__restrict__ n_anchors_dev, size_t cap) {
   const size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (k == 0) {
+  if (k == 0 && !a.aflags && !a.all_hard) {
     // the reference skips leading whitespace first (linear.cpp:227-229); if the first real
-    // position is not an anchor by itself, this thread owns it
+    // position is not an anchor by itself, this thread owns it.  (Only with soft spacing chars under
+    // the class rule: otherwise that position always is an anchor — behind a hard space, or, under
+    // the coverage rule, a word-prefix position no match reaches, since spaces match nothing.)
     size_t q = 0;
     while (q < a.n_text && w_space(a, q)) ++q;
     if (q < a.n_text && q != 0 && !w_anchor(a, q)) walk_from(a, q);
