@@ -463,8 +463,8 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   uint32_t *adep = AD0, *other_dep = AD1;
   bool classified = false;
   // side stream: the anchor list and the cleared emit array only need the class bytes
-  auto launch_anchors = [&] {
-    fork();
+  auto launch_anchors = [&](bool do_fork) {
+    if (do_fork) fork();
     const unsigned atiles = cdiv(n_text, kAnchorTile);
     WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st2));
     hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls,
@@ -479,7 +479,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   // split or the radix passes, which want the bandwidth themselves (14.03 -> 13.97 ms; WP_ANCHOR_LATE=0
   // puts them back next to the split).
   static const bool anchors_late = !(getenv("WP_ANCHOR_LATE") && atoi(getenv("WP_ANCHOR_LATE")) == 0);
-  if (n_text > 0 && !anchors_late) launch_anchors();
+  if (n_text > 0 && !anchors_late) launch_anchors(true);
   // group split of a round: count / spine / apply kernels, or (WP_OPT_FUSED_RERANK, env WP_RERANK=fused)
   // one kernel with a chained scan across tiles
   static const bool env_fused = getenv("WP_RERANK") && std::strcmp(getenv("WP_RERANK"), "fused") == 0;
@@ -614,7 +614,9 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[4], st));
 
   // ---------------- who marks + scanlines ----------------
-  if (n_text > 0 && anchors_late) launch_anchors();
+  // (the side stream may start now, but its launches are issued behind the first scanline kernels so
+  // that the host does not keep the main stream waiting)
+  if (n_text > 0 && anchors_late) fork();
   StepTable steps{};
   MarkView mv{};
   {
@@ -646,6 +648,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       hipLaunchKernelGGL(mark_cover_kernel, dim3(4), dim3(kBlock), 0, st, d_minfo, d_rf, d_rb, M, d_cover_f,
                          d_cover_b);
     }
+    if (n_text > 0 && anchors_late) launch_anchors(false);
     hipLaunchKernelGGL(piece_starts_kernel, dim3(cdiv(std::max(M, 1), kBlock)), dim3(kBlock), 0, st, mv, n, d_ps0);
     const int pc = radix_sort_pairs<uint32_t>(d_ps0, d_pv0, d_ps1, d_pv1, P, 0, bit_length(n), d_radix_tmp, st,
                                               nullptr);
