@@ -100,7 +100,8 @@ typedef struct {
   double ms_total, ms_decode, ms_sa, ms_lcp, ms_scan, ms_walk; /* WP_OPT_STAGE_TIMING */
   double ms_radix_scatter;    /* device time inside radix scatter kernels (HIP events) */
   int64_t n_anchors;          /* start positions of the parallel walk                  */
-  int32_t anchor_mode;        /* 0: class rule, 1: coverage rule (WP_OPT_COVER_ANCHORS) */
+  int32_t anchor_mode;        /* 0: class rule, 1: coverage rule (WP_OPT_COVER_ANCHORS),
+                                 2: class rule + long words by pointer doubling          */
   double ms_h2d, ms_d2h;      /* wp_linear_encode only: host time of the text upload (with
                                  WP_OPT_STAGE_TIMING) and of the id download                */
 } wp_stats;

@@ -248,7 +248,7 @@ def test_single_word_text_random_split_300k():
         gv = W.Vocab(vocab)
         ids = gv.encode(s)
         st = gv.stats()
-        assert st["anchor_mode"] == 1 and st["n_anchors"] == 1
+        assert st["anchor_mode"] == 2 and st["n_anchors"] == 1  # one word, walked by pointer doubling
         exp = _oracle_ids_fast(s, vocab)
         assert np.array_equal(ids, exp)
         assert (len(ids) == 3000) if positive else (ids.tolist() == [-1])
@@ -261,6 +261,18 @@ def test_single_word_text_random_split_300k():
     text = b" ".join(words)
     vocab = ["ab", "##b", "a", ",", "zz"]
     assert np.array_equal(W.Vocab(vocab).encode(text), O.Vocab(vocab).encode(text))
+    assert np.array_equal(_cover_ids(text, vocab), O.Vocab(vocab).encode(text))
+    # base64-like blobs inside ordinary text, BERT-like vocab (every alphanumeric has a ## piece): the
+    # blobs tokenize into ~100 k pieces each; one blob holds a byte no piece covers and becomes [UNK]
+    en, vocab = synth.english_corpus(300_000, seed=23, vocab_size=4000)
+    alnum = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789", dtype=np.uint8)
+    blob = lambda n: alnum[rng.integers(0, len(alnum), n)].tobytes()
+    text = (en[:100_000] + b" " + blob(150_000) + b" " + en[100_000:200_000] + b"\n" + blob(40_000) + b"_" + blob(5)
+            + b" " + blob(3000) + b"\x01" + blob(3000) + b" " + en[200_000:] + b" " + blob(70_000))
+    gv = W.Vocab(vocab)
+    ids = gv.encode(text)
+    assert gv.stats()["anchor_mode"] == 2
+    assert np.array_equal(ids, _oracle_ids_fast(text, vocab))
 
 
 def test_long_whitespace_runs():

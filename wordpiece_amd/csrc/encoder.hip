@@ -15,6 +15,7 @@
 #include <fstream>
 #include <future>
 #include <memory>
+#include <vector>
 
 #include "../../include/wordpiece_amd.h"
 #include "code.h"
@@ -675,7 +676,55 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       n_anchors = c->h_scalars[10];
       max_anchor_gap = c->h_scalars[11];
     }
-    if (v->cover_anchors || max_anchor_gap > kMaxAnchorGap) {
+    const bool all_hard = hv.soft.empty();
+    if (!v->cover_anchors && all_hard && max_anchor_gap > kMaxAnchorGap) {
+      // words longer than a lane should walk (walk.h, "long words"): pointer doubling instead
+      LongWord *d_lw = reinterpret_cast<LongWord *>(LPOS);
+      const uint32_t lw_cap = static_cast<uint32_t>(n_text / kMaxAnchorGap + 2);
+      uint32_t *d_lw_off = LPOS + 2 * static_cast<size_t>(lw_cap);
+      uint32_t *d_lw_fail = d_lw_off + lw_cap + 1;
+      hipLaunchKernelGGL(long_word_collect_kernel, dim3(std::min<size_t>(cdiv(std::max<size_t>(n_anchors, 1), kBlock), 2048)),
+                         dim3(kBlock), 0, st, d_anchors, c->d_scalars + 10, n_text, d_cls, d_lw, lw_cap,
+                         c->d_scalars + 12);
+      WP_LAUNCH_CHECK();
+      fetch_scalars(c, 13);
+      const uint32_t nw = std::min(c->h_scalars[12], lw_cap);
+      if (nw > 0) {
+        std::vector<LongWord> h_lw(nw);
+        WP_HIP(hipMemcpyAsync(h_lw.data(), d_lw, sizeof(LongWord) * nw, hipMemcpyDeviceToHost, st));
+        WP_HIP(hipStreamSynchronize(st));
+        std::vector<uint32_t> h_off(nw + 1);
+        uint64_t total64 = 0;
+        uint32_t longest = 0;
+        for (uint32_t i = 0; i < nw; i++) {
+          h_off[i] = static_cast<uint32_t>(total64);
+          total64 += h_lw[i].end - h_lw[i].begin;
+          longest = std::max(longest, h_lw[i].end - h_lw[i].begin);
+        }
+        h_off[nw] = static_cast<uint32_t>(total64);
+        const uint32_t total = static_cast<uint32_t>(total64);  // <= n_text < 2^31
+        WP_HIP(hipMemcpyAsync(d_lw_off, h_off.data(), sizeof(uint32_t) * (nw + 1), hipMemcpyHostToDevice, st));
+        WP_HIP(hipMemsetAsync(d_lw_fail, 0, sizeof(uint32_t) * nw, st));
+        int32_t *d_lid = reinterpret_cast<int32_t *>(LV0);
+        uint32_t *jump_a = LV1, *jump_b = reinterpret_cast<uint32_t *>(K0);
+        uint8_t *d_mark = reinterpret_cast<uint8_t *>(K1);
+        const dim3 grid(cdiv(total, kBlock));
+        hipLaunchKernelGGL(long_word_next_kernel, grid, dim3(kBlock), 0, st, wa, d_lw, d_lw_off, nw, total, d_lid, jump_a,
+                           d_mark);
+        WP_HIP(hipStreamSynchronize(st));  // h_off is a stack-owned upload source
+        for (uint32_t reach = 1; reach < longest; reach *= 2) {  // after r rounds: chain prefixes of length 2^r
+          hipLaunchKernelGGL(long_word_mark_kernel, grid, dim3(kBlock), 0, st, jump_a, total, d_mark);
+          hipLaunchKernelGGL(long_word_double_kernel, grid, dim3(kBlock), 0, st, jump_a, total, jump_b);
+          std::swap(jump_a, jump_b);
+        }
+        hipLaunchKernelGGL(long_word_mark_kernel, grid, dim3(kBlock), 0, st, jump_a, total, d_mark);
+        hipLaunchKernelGGL(long_word_fail_kernel, grid, dim3(kBlock), 0, st, d_lid, d_mark, d_lw_off, nw, total, d_lw_fail);
+        hipLaunchKernelGGL(long_word_emit_kernel, grid, dim3(kBlock), 0, st, wa, d_lw, d_lw_off, nw, total, d_lid, d_mark,
+                           d_lw_fail);
+        WP_LAUNCH_CHECK();
+        S.anchor_mode = 2;
+      }
+    } else if (v->cover_anchors || max_anchor_gap > kMaxAnchorGap) {
       // long stretches without class-rule anchors ("soft" spacing chars): anchors from the matches
       // themselves (walk.h).  The large-group buffers of the suffix sort are free by now.
       uint32_t *d_reach = LV0, *d_reach_tiles = LPOS;

@@ -334,6 +334,114 @@ __global__ __launch_bounds__(1024) void suffix_min_kernel(uint32_t *__restrict__
   }
 }
 
+// ---- long words -------------------------------------------------------------------------------------
+// With only hard spacing chars every word is walked on its own, but a lane still takes its word token
+// by token: a megabyte of base64 or the reference's 10 M-character single-word stress
+// (tests.cpp:266-272) would keep one lane busy for 0.1-1 s.  Words longer than kMaxAnchorGap are
+// therefore taken out of the lane walk: the positions of all such words are laid out in one compact
+// index space, every position gets its successor j + len(best token) (terminal: no token = the
+// word fails, or the word's end), the chain from each word start is marked by pointer doubling
+// (log2(longest word) rounds of "mark my successor; successor <- successor of successor"), and the
+// marked positions emit their ids in parallel — or, if the chain reached a position without a token,
+// the single [UNK] of linear.cpp:257-266.
+struct LongWord {
+  uint32_t begin, end;  // [this anchor, next anchor): the word and the blanks behind it
+};
+constexpr uint32_t kAnchorSkip = 0x80000000u;  // flag in the anchor list: not for the lane walk
+
+__global__ __launch_bounds__(kBlock) void long_word_collect_kernel(uint32_t *__restrict__ anchors,
+                                                                   const uint32_t *__restrict__ n_anchors_dev,
+                                                                   size_t n_text, const uint8_t *__restrict__ cls,
+                                                                   LongWord *__restrict__ list, uint32_t cap,
+                                                                   uint32_t *__restrict__ count) {
+  const size_t na = *n_anchors_dev;
+  for (size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; k < na;
+       k += static_cast<size_t>(gridDim.x) * kBlock) {
+    const uint32_t lo = anchors[k] & ~kAnchorSkip;
+    const uint32_t hi = k + 1 < na ? (anchors[k + 1] & ~kAnchorSkip) : static_cast<uint32_t>(n_text);
+    if (hi - lo <= kMaxAnchorGap) continue;
+    uint32_t q = lo;
+    const uint32_t stop = min(hi, lo + static_cast<uint32_t>(kMaxAnchorGap) + 1u);
+    while (q < stop && !(cls[q] & kClsSpace)) q++;
+    if (q - lo <= kMaxAnchorGap) continue;  // a short word in front of a long blank run
+    const uint32_t i = atomicAdd(count, 1u);
+    if (i < cap) list[i] = LongWord{lo, hi};
+    anchors[k] = lo | kAnchorSkip;
+  }
+}
+
+__device__ __forceinline__ uint32_t long_word_of(const uint32_t *__restrict__ off, uint32_t nw, uint32_t j) {
+  uint32_t lo = 0, hi = nw;  // last word with off[w] <= j
+  while (hi - lo > 1) {
+    const uint32_t md = (lo + hi) >> 1;
+    if (off[md] <= j) lo = md; else hi = md;
+  }
+  return lo;
+}
+
+// id[j]: >= 0 token, -1 no token (the word fails here), -2 blank (the word is over); jump[j]: successor
+// in the compact index space, j itself for the terminal cases; mark[j] = 1 at the word starts
+__global__ __launch_bounds__(kBlock) void long_word_next_kernel(WalkArgs a, const LongWord *__restrict__ list,
+                                                                const uint32_t *__restrict__ off, uint32_t nw,
+                                                                uint32_t total, int32_t *__restrict__ id_out,
+                                                                uint32_t *__restrict__ jump,
+                                                                uint8_t *__restrict__ mark) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= total) return;
+  const uint32_t w = long_word_of(off, nw, j);
+  const LongWord lw = list[w];
+  const size_t p = static_cast<size_t>(lw.begin) + (j - off[w]);
+  int32_t id = -2;
+  uint32_t nx = j;
+  if (!w_space(a, p)) {
+    const int k = step_lookup(a.steps, rank_of(a.rank[p]));
+    id = w_word_prefix(a, p) ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
+    if (id != -1) {
+      const size_t q = p + static_cast<size_t>(a.tok_len[id]);
+      if (q < lw.end) nx = j + static_cast<uint32_t>(a.tok_len[id]);  // (q == end: the last token of the range)
+    }
+  }
+  id_out[j] = id;
+  jump[j] = nx;
+  mark[j] = j == off[w] ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void long_word_mark_kernel(const uint32_t *__restrict__ jump, uint32_t total,
+                                                                uint8_t *__restrict__ mark) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j < total && mark[j]) mark[jump[j]] = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void long_word_double_kernel(const uint32_t *__restrict__ jump_in, uint32_t total,
+                                                                  uint32_t *__restrict__ jump_out) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j < total) jump_out[j] = jump_in[jump_in[j]];
+}
+
+__global__ __launch_bounds__(kBlock) void long_word_fail_kernel(const int32_t *__restrict__ id, const uint8_t *__restrict__ mark,
+                                                                const uint32_t *__restrict__ off, uint32_t nw,
+                                                                uint32_t total, uint32_t *__restrict__ word_fail) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j < total && mark[j] && id[j] == -1) word_fail[long_word_of(off, nw, j)] = 1u;
+}
+
+__global__ __launch_bounds__(kBlock) void long_word_emit_kernel(WalkArgs a, const LongWord *__restrict__ list,
+                                                                const uint32_t *__restrict__ off, uint32_t nw,
+                                                                uint32_t total, const int32_t *__restrict__ id,
+                                                                const uint8_t *__restrict__ mark,
+                                                                const uint32_t *__restrict__ word_fail) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= total || !mark[j]) return;
+  const uint32_t w = long_word_of(off, nw, j);
+  const size_t p = static_cast<size_t>(list[w].begin) + (j - off[w]);
+  const int32_t t = id[j];
+  if (word_fail[w]) {
+    if (t == -1) a.emit[p] = a.unk_id;  // the one [UNK] of the word, where its chain broke
+  } else if (t >= 0) {
+    a.emit[p] = t;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a, const uint32_t *__restrict__ anchors,
                                                       const uint32_t *__restrict__ n_anchors_dev, size_t cap) {
   const size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -347,7 +455,9 @@ __global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a, const uint32_t
     if (q < a.n_text && q != 0 && !w_anchor(a, q)) walk_from(a, q);
   }
   if (k >= cap || k >= *n_anchors_dev) return;
-  walk_from(a, anchors[k]);
+  const uint32_t start = anchors[k];
+  if (start & kAnchorSkip) return;  // a long word: long_word_* kernels
+  walk_from(a, start);
 }
 
 // ---- compaction of emit[] into the id stream ----------------------------------------------------
