@@ -292,6 +292,55 @@ def test_long_whitespace_runs():
     assert np.array_equal(_cover_ids(text2, vocab2), O.Vocab(vocab2).encode(text2))
 
 
+def test_fuzz_long_runs_all_anchor_modes():
+    """Random vocabularies (with and without spacing chars inside tokens) over texts that contain long
+    words, long blank runs and CJK stretches: every walk variant (class rule, coverage rule, long-word
+    doubling, [UNK] skips) against the oracle."""
+    rng = random.Random(20260)
+    letters = "abcdefgh"
+    modes = set()
+    for case in range(int(os.environ.get("WP_FUZZ_CASES", "120"))):
+        soft = case % 3 == 0
+        vocab = set()
+        for _ in range(rng.randint(3, 25)):
+            w = "".join(rng.choice(letters + (",中" if rng.random() < 0.3 else "")) for _ in range(rng.randint(1, 5)))
+            if soft and rng.random() < 0.3:
+                w = w[:1] + rng.choice([" ", ",", "中"]) + w[1:]
+            vocab.add(("##" if rng.random() < 0.4 else "") + w)
+        for c in letters[:rng.randint(0, 8)]:
+            vocab.add(c)
+            vocab.add("##" + c)
+        if rng.random() < 0.5:
+            vocab.add("[UNK]")
+        vocab = sorted(vocab)
+        rng.shuffle(vocab)
+        try:
+            ov = O.Vocab(vocab)
+        except O.OracleError:
+            continue
+        parts = []
+        for _ in range(rng.randint(3, 12)):
+            kind = rng.random()
+            if kind < 0.3:
+                parts.append("".join(rng.choice(letters) for _ in range(rng.randint(2100, 5000))))  # long word
+            elif kind < 0.45:
+                parts.append(rng.choice([" ", "\n", " \t"]) * rng.randint(2100, 4000))               # long blank run
+            elif kind < 0.55:
+                parts.append("".join(rng.choice("中文字") for _ in range(rng.randint(100, 3000))))
+            else:
+                parts.append(" ".join("".join(rng.choice(letters + ",") for _ in range(rng.randint(1, 9)))
+                                      for _ in range(rng.randint(5, 200))))
+            parts.append(rng.choice([" ", "", ",", "\n"]))
+        text = "".join(parts).encode("utf8")
+        exp = ov.encode(text)
+        gv = W.Vocab(vocab)
+        got = gv.encode(text)
+        modes.add(gv.stats()["anchor_mode"])
+        assert np.array_equal(got, exp), (case, vocab)
+        assert np.array_equal(_cover_ids(text, vocab), exp), (case, vocab, "coverage rule")
+    assert modes == {0, 1, 2} or modes == {1, 2}
+
+
 def test_kasai_kernel_gives_same_lcp():
     text, vocab = synth.english_corpus(300_000, seed=8, vocab_size=3000)
     d = O.Vocab(vocab).encode_debug(text)
