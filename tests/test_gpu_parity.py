@@ -341,6 +341,19 @@ def test_fuzz_long_runs_all_anchor_modes():
     assert modes == {0, 1, 2} or modes == {1, 2}
 
 
+def test_periodic_text_full_depth_all_stages():
+    """Highly repetitive text: two giant groups that stay tied for log2(n) rounds (the large-group
+    path in every round), full depth — SA, rank, LCP and ids bit for bit."""
+    text = ("ab" * 60_000 + " " + "abc" * 30_000 + " " + "a" * 50_000).encode()
+    vocab = ["ab", "##ab", "abc", "##abc", "a", "##a", "##b", "##c", "[UNK]"]
+    st = check_all_stages(text, vocab, "periodic")
+    assert st["n_ids"] > 0
+    gv = W.Vocab(vocab)
+    gv.set_option(W.WP_OPT_FULL_DEPTH, 1)
+    gv.encode(text)
+    assert gv.stats()["rounds"] >= 12
+
+
 def test_kasai_kernel_gives_same_lcp():
     text, vocab = synth.english_corpus(300_000, seed=8, vocab_size=3000)
     d = O.Vocab(vocab).encode_debug(text)
