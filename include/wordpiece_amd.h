@@ -83,11 +83,13 @@ int wp_linear_encode_external(const char *text_file, const char *vocab_file, con
 #define WP_OPT_LCP_KASAI 5    /* 1: build LCP with the chunked Kasai kernel (linear.cpp:18-70)
                                  instead of deriving it inside the doubling rounds */
 #define WP_OPT_FUSED_RERANK 6 /* 1: single-pass group split (chained scan across tiles) instead of
-                                 the default count / spine / apply kernels; same results, same
-                                 speed on MI355X ("measured dead ends") */
+                                 the default count / prefix / apply kernels; same results, slightly
+                                 slower on MI355X ("measured dead ends") */
 #define WP_OPT_COVER_ANCHORS 7 /* 1: always derive the walk's start positions from the matches
-                                 (default: only when the class rule leaves gaps > 2048 positions,
-                                 e.g. CJK text with multi-char CJK tokens) */
+                                 (default: only when the class rule leaves gaps > 2048 positions
+                                 and some spacing char occurs inside a multi-char token, e.g. CJK
+                                 text with multi-char CJK tokens; long words of ordinary
+                                 vocabularies are walked by pointer doubling instead) */
 int wp_set_option(wp_vocab *v, int option, int64_t value);
 
 /* ---- statistics of the last encode on this handle (for bench.py / roofline) ---- */
