@@ -1,5 +1,11 @@
 // code.h — order-preserving variable-length symbol code for the round-0 sort keys.
 //
+// (Alphabets of more than 255 symbols — mixed scripts — use a *split* code: the Garsia–Wachs code
+// is built over the high part of the dense symbol id (symbol >> lo_bits, at most 256 values) and the
+// low lo_bits follow verbatim.  Dense ids are order preserving, frequent scripts occupy few high
+// values, so Latin / Cyrillic symbols cost 7-8 bits and CJK 12-13 instead of 13 for everything; the
+// code stays prefix free and order preserving.)
+//
 // Round 0 of the suffix sort packs the beginning of every suffix into one 63-bit key.  With a
 // fixed b bits per symbol that is floor(63/b) symbols (9 for English text).  An *alphabetic*
 // prefix code (Garsia–Wachs: optimal among codes whose codeword order equals the symbol order)
@@ -24,6 +30,8 @@ constexpr int kMaxCodeLen = 12;  // decode table: 2^12 entries (first codeword l
 
 struct SymbolCode {
   int uniform_bits = 0;            // > 0: every symbol takes this many bits (fixed-width mode)
+  int lo_bits = 0;                 // split code (alphabets > 255): the tables code symbol >> lo_bits,
+                                   // the low lo_bits of the symbol follow the codeword verbatim
   std::vector<uint16_t> cw;        // codeword of dense symbol s (0 = past-the-end padding), right aligned
   std::vector<uint8_t> len;        // its length in bits
   std::vector<uint8_t> first_len;  // [4096]: length of the first codeword of a 12-bit window

@@ -110,15 +110,17 @@ template <typename SymT>
 __global__ __launch_bounds__(kBlock) void decode_write_kernel(
     const uint8_t *__restrict__ text, size_t nbytes, const uint32_t *__restrict__ tile_prefix,
     const uint32_t *__restrict__ lut_excl, SymT *__restrict__ sym, uint8_t *__restrict__ cls,
-    uint32_t *__restrict__ cps_dbg, const uint32_t *__restrict__ soft, int nsoft, uint32_t *__restrict__ sym_hist) {
+    uint32_t *__restrict__ cps_dbg, const uint32_t *__restrict__ soft, int nsoft, uint32_t *__restrict__ sym_hist,
+    int hist_shift) {
   __shared__ uint32_t sm[8];
   __shared__ uint32_t scp[kDecTile];
   __shared__ uint32_t shist[256];
   __shared__ uint16_t s_ascii[128];  // (class byte << 8) | dense symbol of the ASCII code points
   // The symbol histogram only steers the code lengths (any histogram gives a valid code), so it is
   // taken from every 16th tile of large inputs: the per-tile flush is ~50 same-address atomics.
-  const bool sampled = sizeof(SymT) == 1 && (gridDim.x < 256 || (blockIdx.x & 15) == 0);
-  if (sizeof(SymT) == 1) shist[threadIdx.x] = 0;
+  // (wide alphabets: the histogram is over symbol >> hist_shift, the coded part of the split code)
+  const bool sampled = sym_hist != nullptr && (gridDim.x < 256 || (blockIdx.x & 15) == 0);
+  shist[threadIdx.x] = 0;
   auto class_of = [&](uint32_t c) {
     uint8_t f = 0;
     if (is_space(c)) f |= kClsSpace;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void decode_write_kernel(
       f = class_of(c);
     }
     sym[out_base + k] = static_cast<SymT>(sv);
-    if (sampled) atomicAdd(&shist[sv & 255u], 1u);
+    if (sampled) atomicAdd(&shist[(sv >> hist_shift) & 255u], 1u);
     if (cps_dbg) cps_dbg[out_base + k] = c;
     cls[out_base + k] = f;
   }
@@ -222,7 +224,7 @@ struct DevCode {
   const uint16_t *cw;
   const uint8_t *len;
   const uint8_t *first_len;  // the kDecodeTableBytes of count_key_symbols' table (bmask u16[4096])
-  int uniform_bits;
+  int uniform_bits;  // > 0: fixed width; 0: variable-length code; < 0: split code with lo_bits = -uniform_bits
 };
 constexpr int kDecodeTableBytes = 2 * 4096;
 
@@ -230,9 +232,21 @@ constexpr int kDecodeTableBytes = 2 * 4096;
 // tab = bmask u16[4096] (code.h): the codeword ends inside a 12-bit window as a bit mask, so one
 // table step counts and skips all whole codewords of the window that still fit.
 __device__ __forceinline__ int count_key_symbols(uint64_t key, int t, const uint8_t *tab, int uniform_bits) {
-  if (uniform_bits) return t / uniform_bits;
+  if (uniform_bits > 0) return t / uniform_bits;
   const uint16_t *bmask = reinterpret_cast<const uint16_t *>(tab);
   int pos = 0, cnt = 0;
+  if (uniform_bits < 0) {  // split code: codeword of the high part, then -uniform_bits verbatim bits
+    const int lo = -uniform_bits;
+    while (pos < t) {
+      const int sh = kKeyBits - pos - 12;
+      const uint32_t w = static_cast<uint32_t>(sh >= 0 ? (key >> sh) : (key << -sh)) & 0xfffu;
+      const int l = __ffs(static_cast<int>(bmask[w])) + lo;  // first codeword of the window + low bits
+      if (pos + l > t) break;
+      pos += l;
+      cnt++;
+    }
+    return cnt;
+  }
   while (pos < t) {
     const int sh = kKeyBits - pos - 12;
     const uint32_t w = static_cast<uint32_t>(sh >= 0 ? (key >> sh) : (key << -sh)) & 0xfffu;
@@ -269,7 +283,9 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
     size_t i = base + k;
     ss[key_pad(k)] = i < n ? static_cast<uint32_t>(sym[i]) : 0u;
   }
-  const int ub = code.uniform_bits;
+  const int ub = code.uniform_bits > 0 ? code.uniform_bits : 0;
+  const int lo = code.uniform_bits < 0 ? -code.uniform_bits : 0;  // split code: verbatim low bits
+  const uint32_t lomask = (1u << lo) - 1u;
   if (!ub) stab[threadIdx.x] = (static_cast<uint32_t>(code.len[threadIdx.x]) << 16) | code.cw[threadIdx.x];
   __syncthreads();
   const int p0 = threadIdx.x * kKeyItems;
@@ -279,9 +295,9 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
     while (used < kKeyBits) {  // key of the lane's last position
       const uint32_t sv = ss[key_pad(q)];
       q++;
-      const uint32_t e = ub ? 0u : stab[sv];
-      const int l = ub ? ub : static_cast<int>(e >> 16);
-      const uint32_t c = ub ? sv : (e & 0xffffu);
+      const uint32_t e = ub ? 0u : stab[sv >> lo];
+      const int l = ub ? ub : static_cast<int>(e >> 16) + lo;
+      const uint32_t c = ub ? sv : (((e & 0xffffu) << lo) | (sv & lomask));
       const int take = min(l, kKeyBits - used);
       key = (key << take) | (c >> (l - take));
       used += take;
@@ -290,9 +306,9 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
 #pragma unroll
     for (int j = kKeyItems - 2; j >= 0; j--) {
       const uint32_t sv = ss[key_pad(p0 + j)];
-      const uint32_t e = ub ? 0u : stab[sv];
-      const int l = ub ? ub : static_cast<int>(e >> 16);
-      const uint64_t c = ub ? sv : (e & 0xffffu);
+      const uint32_t e = ub ? 0u : stab[sv >> lo];
+      const int l = ub ? ub : static_cast<int>(e >> 16) + lo;
+      const uint64_t c = ub ? sv : (((e & 0xffffu) << lo) | (sv & lomask));
       key = (c << (kKeyBits - l)) | (key >> l);
       skey[key_pad(p0 + j)] = key;
     }

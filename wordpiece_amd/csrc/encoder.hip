@@ -389,27 +389,34 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   }
 
   // ---------------- S build: dense symbols, symbol code, round-0 keys ----------------
+  static const bool allow_variable = !(getenv("WP_FIXED_CODE") && atoi(getenv("WP_FIXED_CODE")) != 0);
+  // alphabets > 255: the code covers symbol >> lo_bits (<= 256 values), the low bits follow verbatim
+  const int lo_bits = sizeof(SymT) == 1 ? 0 : std::max(0, bits - 8);
   WP_HIP(hipMemsetAsync(c->d_symhist, 0, sizeof(uint32_t) * 256, st));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(decode_write_kernel<SymT>), dim3(cdiv(nbytes, kDecTile)), dim3(kBlock), 0, st,
                      d_text, nbytes, d_tile_prefix, c->d_lut, d_sym, d_cls, d_cps, c->d_soft,
-                     static_cast<int>(hv.soft.size()), c->d_symhist);
+                     static_cast<int>(hv.soft.size()), allow_variable ? c->d_symhist : nullptr, lo_bits);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(map_vocab_symbols_kernel<SymT>), dim3(cdiv(n - n_text, kBlock)), dim3(kBlock), 0,
                      st, c->d_stream, n_text, n, c->d_lut, d_sym);
   SymbolCode code;
-  static const bool allow_variable = !(getenv("WP_FIXED_CODE") && atoi(getenv("WP_FIXED_CODE")) != 0);
-  if (sizeof(SymT) == 1 && allow_variable) {
-    // symbol frequencies -> optimal order-preserving code (host, <= 256 symbols) -> device tables
+  if (allow_variable) {
+    // frequencies of symbol >> lo_bits -> optimal order-preserving code (host, <= 256 items) -> device tables
     std::vector<uint32_t> h32(256);
     WP_HIP(hipMemcpyAsync(h32.data(), c->d_symhist, sizeof(uint32_t) * 256, hipMemcpyDeviceToHost, st));
     WP_HIP(hipStreamSynchronize(st));
-    const size_t nsym = static_cast<size_t>(S.alphabet) + 1;  // dense symbols 0..sigma
-    std::vector<uint64_t> freq(nsym);
-    for (size_t i = 0; i < nsym; i++) freq[i] = h32[i];
+    const size_t nitems = (static_cast<size_t>(S.alphabet) >> lo_bits) + 1;  // dense symbols 0..sigma
+    std::vector<uint64_t> freq(nitems);
+    for (size_t i = 0; i < nitems; i++) freq[i] = h32[i];
     code = build_symbol_code(freq, bits, true);
+    if (!code.uniform_bits) {
+      code.lo_bits = lo_bits;
+      code.avg_bits += lo_bits;
+    }
   } else {
     code = build_symbol_code({}, bits, false);
   }
-  DevCode dcode{reinterpret_cast<const uint16_t *>(c->d_code), c->d_code + 512, c->d_code + 768, code.uniform_bits};
+  DevCode dcode{reinterpret_cast<const uint16_t *>(c->d_code), c->d_code + 512, c->d_code + 768,
+                code.uniform_bits ? code.uniform_bits : -code.lo_bits};
   if (!code.uniform_bits) {
     std::vector<uint8_t> blob(512 + 256 + kDecodeTableBytes, 0);
     std::memcpy(blob.data(), code.cw.data(), code.cw.size() * sizeof(uint16_t));

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
                                                             RerankAgg *__restrict__ agg) {
   __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
   __shared__ uint8_t s_fl[kDecodeTableBytes];
-  if (ROUND0 && !uniform_bits) {
+  if (ROUND0 && uniform_bits <= 0) {
     for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
       reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
     }
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     uint32_t *__restrict__ ghead, uint32_t *__restrict__ gdepth, uint32_t *__restrict__ totals) {
   __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
   __shared__ uint8_t s_fl[kDecodeTableBytes];
-  if (ROUND0 && !uniform_bits) {
+  if (ROUND0 && uniform_bits <= 0) {
     for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
       reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
     }
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void rerank_fused_kernel(
   __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
   __shared__ uint32_t s_tile, s_pre[3];
   __shared__ uint8_t s_fl[kDecodeTableBytes];
-  if (ROUND0 && !uniform_bits) {
+  if (ROUND0 && uniform_bits <= 0) {
     for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
       reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
     }
