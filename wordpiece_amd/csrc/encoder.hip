@@ -653,7 +653,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                          d_rf, d_rb);
     }
     if (M > 0) {
-      hipLaunchKernelGGL(mark_cover_kernel, dim3(4), dim3(kBlock), 0, st, d_minfo, d_rf, d_rb, M, d_cover_f,
+      hipLaunchKernelGGL(mark_cover_kernel, dim3(4), dim3(kCoverThreads), 0, st, d_minfo, d_rf, d_rb, M, d_cover_f,
                          d_cover_b);
     }
     if (n_text > 0 && anchors_late) launch_anchors(false);
