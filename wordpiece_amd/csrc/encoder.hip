@@ -85,7 +85,7 @@ struct Context {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // side stream: latency-bound helpers overlap the bandwidth-bound kernels
-  hipEvent_t evs[2] = {};         // fork / join
+  hipEvent_t evs[3] = {};         // fork / join / scalars fetched
   // vocab tables on the device
   uint32_t *d_stream = nullptr, *d_elig_start = nullptr, *d_elig_info = nullptr, *d_soft = nullptr;
   int32_t *d_elig_id = nullptr, *d_tok_len = nullptr;
@@ -456,8 +456,9 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   auto store_ranks = [&](uint32_t *dst, uint32_t *val, uint32_t *t_dst, uint32_t *t_val, size_t m) {
     if (bin_bits > 0 && m >= (1u << 22)) {
       const int hb = bit_length(n - 1);
+      // (the top bits of a text position are uniformly distributed: histogram by LDS atomics)
       const int bc = radix_sort_pairs<uint32_t>(dst, val, t_dst, t_val, m, std::max(0, hb - bin_bits), hb, d_radix_tmp,
-                                                st, nullptr);
+                                                st, nullptr, false, hb + 1);
       hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), sp_lds, st, bc ? t_dst : dst,
                          bc ? t_val : val, m, d_rank, 1);
     } else {
@@ -529,9 +530,26 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     classified = classify_groups(n);
     join();
   }
-  fetch_scalars(c, 12);
-  size_t n_anchors = n_text > 0 ? c->h_scalars[10] : 0;  // (the side stream was joined above)
-  size_t max_anchor_gap = n_text > 0 ? c->h_scalars[11] : 0;
+  uint32_t *avals = other_vals;  // active list values live in the vals buffer the sort did not end in
+  uint32_t *spare_vals = vals;
+  const int rb = bit_length(n);  // rank+1 <= n
+  // Between two rounds the host needs the new list sizes (grids, large-group path).  The copy of the
+  // scalars and the LDS segmented sort of the next round are queued first — the sort reads its sizes on
+  // the device and gets a grid for the largest possible list — and only then does the host wait for the
+  // copy: the round trip hides behind the sort instead of idling the GPU.
+  auto next_round_begin = [&](size_t upper) {
+    WP_HIP(hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(uint32_t) * 12, hipMemcpyDeviceToHost, st));
+    WP_HIP(hipEventRecord(c->evs[2], st));
+    fork();  // the large-group path of the next round (side stream) may start from here
+    if (upper > 0) {
+      hipLaunchKernelGGL(local_sort_kernel, dim3(cdiv(upper, kLsT)), dim3(kBlock), 0, st, avals, AG, adep,
+                         c->d_scalars + 4, d_ghead, d_rank, n, rb, K0, spare_vals);
+    }
+    WP_HIP(hipEventSynchronize(c->evs[2]));
+  };
+  next_round_begin(n);
+  size_t n_anchors = n_text > 0 && !anchors_late ? c->h_scalars[10] : 0;  // (the side stream was joined above)
+  size_t max_anchor_gap = n_text > 0 && !anchors_late ? c->h_scalars[11] : 0;
   size_t n_act = c->h_scalars[4], n_groups = c->h_scalars[5];
   size_t n_large_groups = classified ? c->h_scalars[6] : 0, n_large = classified ? c->h_scalars[7] : 0;
   static const bool group_stats = getenv("WP_GROUP_STATS") && atoi(getenv("WP_GROUP_STATS")) != 0;
@@ -548,17 +566,12 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   }
   int rounds = 1;
   S.active_per_round[0] = static_cast<int64_t>(n);
-  uint32_t *avals = other_vals;  // active list values live in the vals buffer the sort did not end in
-  uint32_t *spare_vals = vals;
-  const int rb = bit_length(n);  // rank+1 <= n
   while (n_act > 0) {
     if (rounds < 40) S.active_per_round[rounds] = static_cast<int64_t>(n_act);
-    // small groups: one LDS-resident segmented sort per window of the list
+    // small groups: one LDS-resident segmented sort per window of the list (already queued by
+    // next_round_begin: avals -> (K0, spare_vals))
     uint64_t *skeys = K0, *kfree = K1;
     uint32_t *svals = spare_vals, *nvals = avals;  // avals is free again once the sorts have consumed it
-    if (n_large > 0) fork();
-    hipLaunchKernelGGL(local_sort_kernel, dim3(cdiv(n_act, kLsT)), dim3(kBlock), 0, st, avals, AG, adep, n_act,
-                       d_ghead, static_cast<uint32_t>(n_groups), d_rank, n, rb, skeys, svals);
     if (n_large > 0) {  // large groups (side stream, disjoint list positions): extract, global radix sort on
                         // (dense large id, second key), write back
       const int lgb = bit_length(n_large_groups > 0 ? n_large_groups - 1 : 0);
@@ -599,17 +612,18 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     WP_LAUNCH_CHECK();
     classified = classify_groups(n_act);
     join();
-    fetch_scalars(c, 8);
-    n_act = c->h_scalars[4];
-    n_groups = c->h_scalars[5];
-    n_large_groups = classified ? c->h_scalars[6] : 0;
-    n_large = classified ? c->h_scalars[7] : 0;
     std::swap(slots, other_slots);
     std::swap(adep, other_dep);
     avals = nvals;
     spare_vals = svals;
+    next_round_begin(n_act);  // (the next list is at most as long as this one)
+    n_act = c->h_scalars[4];
+    n_groups = c->h_scalars[5];
+    n_large_groups = classified ? c->h_scalars[6] : 0;
+    n_large = classified ? c->h_scalars[7] : 0;
     rounds++;
   }
+  (void)n_groups;
   S.rounds = rounds;
   // every tie that is left shares at least need_depth symbols (depth-capped mode)
   S.sorted_depth = full ? 0x7fffffff : static_cast<int32_t>(need_depth);

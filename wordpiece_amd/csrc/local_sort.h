@@ -141,11 +141,18 @@ __global__ __launch_bounds__(kBlock) void large_writeback_kernel(const uint64_t 
 
 __global__ __launch_bounds__(kBlock) void local_sort_kernel(const uint32_t *__restrict__ aval,
                                                             const uint32_t *__restrict__ agid,
-                                                            const uint32_t *__restrict__ adep, size_t m,
-                                                            const uint32_t *__restrict__ ghead, uint32_t n_groups,
+                                                            const uint32_t *__restrict__ adep,
+                                                            const uint32_t *__restrict__ sizes_dev,
+                                                            const uint32_t *__restrict__ ghead,
                                                             const RankEntry *__restrict__ rank, size_t n, int rbits,
                                                             uint64_t *__restrict__ kout,
                                                             uint32_t *__restrict__ vout) {
+  // sizes_dev[0] = list length, sizes_dev[1] = number of groups: read on the device, so that the
+  // kernel can be queued (with a grid for the largest possible list) while the host is still waiting
+  // for the same numbers; workgroups behind the list leave at once
+  const size_t m = sizes_dev[0];
+  const uint32_t n_groups = sizes_dev[1];
+  if (static_cast<size_t>(blockIdx.x) * kLsT >= m) return;
   constexpr int WAVES = kBlock / kWave;
   __shared__ uint64_t skey[kLsCap];
   __shared__ uint32_t sval[kLsCap];
