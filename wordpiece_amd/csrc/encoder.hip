@@ -388,6 +388,24 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     if (pass == 0) ar.commit();
   }
 
+  // side stream: the anchor list and the cleared emit array only need the class bytes
+  auto launch_anchors = [&](bool do_fork) {
+    if (do_fork) fork();
+    const unsigned atiles = cdiv(n_text, kAnchorTile);
+    WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st2));
+    hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls,
+                       static_cast<const uint8_t *>(nullptr), n_text, d_anchor_cnt);
+    device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st2);
+    hipLaunchKernelGGL(anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls,
+                       static_cast<const uint8_t *>(nullptr), n_text, d_anchor_cnt, d_anchors);
+    hipLaunchKernelGGL(anchor_gap_kernel, dim3(std::min<size_t>(atiles, 1024)), dim3(kBlock), 0, st2, d_anchors,
+                       c->d_scalars + 10, n_text, d_cls, hv.soft.empty() ? 1 : 0, c->d_scalars + 11);
+  };
+  // Where they run (WP_ANCHOR_AT): 0 = next to the key build and the host's code construction
+  // (compute-bound / idle GPU), 1 = next to the round-0 split, 2 = next to the scanline stage (small
+  // latency-bound kernels).  Not next to the radix passes, which want the bandwidth themselves.
+  static const int anchor_at = getenv("WP_ANCHOR_AT") ? atoi(getenv("WP_ANCHOR_AT")) : 2;
+  const bool anchors_late = anchor_at != 1;  // the counts are fetched right before the walk
   // ---------------- S build: dense symbols, symbol code, round-0 keys ----------------
   static const bool allow_variable = !(getenv("WP_FIXED_CODE") && atoi(getenv("WP_FIXED_CODE")) != 0);
   // alphabets > 255: the code covers symbol >> lo_bits (<= 256 values), the low bits follow verbatim
@@ -398,6 +416,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
                      static_cast<int>(hv.soft.size()), allow_variable ? c->d_symhist : nullptr, lo_bits);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(map_vocab_symbols_kernel<SymT>), dim3(cdiv(n - n_text, kBlock)), dim3(kBlock), 0,
                      st, c->d_stream, n_text, n, c->d_lut, d_sym);
+  if (n_text > 0 && anchor_at == 0) launch_anchors(true);
   SymbolCode code;
   if (allow_variable) {
     // frequencies of symbol >> lo_bits -> optimal order-preserving code (host, <= 256 items) -> device tables
@@ -473,24 +492,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   uint32_t *slots = AS0, *other_slots = AS1;
   uint32_t *adep = AD0, *other_dep = AD1;
   bool classified = false;
-  // side stream: the anchor list and the cleared emit array only need the class bytes
-  auto launch_anchors = [&](bool do_fork) {
-    if (do_fork) fork();
-    const unsigned atiles = cdiv(n_text, kAnchorTile);
-    WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st2));
-    hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls,
-                       static_cast<const uint8_t *>(nullptr), n_text, d_anchor_cnt);
-    device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st2);
-    hipLaunchKernelGGL(anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls,
-                       static_cast<const uint8_t *>(nullptr), n_text, d_anchor_cnt, d_anchors);
-    hipLaunchKernelGGL(anchor_gap_kernel, dim3(std::min<size_t>(atiles, 1024)), dim3(kBlock), 0, st2, d_anchors,
-                       c->d_scalars + 10, n_text, d_cls, hv.soft.empty() ? 1 : 0, c->d_scalars + 11);
-  };
-  // They run next to the scanline stage (small latency-bound kernels) rather than next to the round-0
-  // split or the radix passes, which want the bandwidth themselves (14.03 -> 13.97 ms; WP_ANCHOR_LATE=0
-  // puts them back next to the split).
-  static const bool anchors_late = !(getenv("WP_ANCHOR_LATE") && atoi(getenv("WP_ANCHOR_LATE")) == 0);
-  if (n_text > 0 && !anchors_late) launch_anchors(true);
+  if (n_text > 0 && anchor_at == 1) launch_anchors(true);
   // group split of a round: count / spine / apply kernels, or (WP_OPT_FUSED_RERANK, env WP_RERANK=fused)
   // one kernel with a chained scan across tiles
   static const bool env_fused = getenv("WP_RERANK") && std::strcmp(getenv("WP_RERANK"), "fused") == 0;
@@ -640,7 +642,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   // ---------------- who marks + scanlines ----------------
   // (the side stream may start now, but its launches are issued behind the first scanline kernels so
   // that the host does not keep the main stream waiting)
-  if (n_text > 0 && anchors_late) fork();
+  if (n_text > 0 && anchor_at == 2) fork();
   StepTable steps{};
   MarkView mv{};
   {
@@ -672,7 +674,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       hipLaunchKernelGGL(mark_cover_kernel, dim3(4), dim3(kCoverThreads), 0, st, d_minfo, d_rf, d_rb, M, d_cover_f,
                          d_cover_b);
     }
-    if (n_text > 0 && anchors_late) launch_anchors(false);
+    if (n_text > 0 && anchor_at == 2) launch_anchors(false);
     hipLaunchKernelGGL(piece_starts_kernel, dim3(cdiv(std::max(M, 1), kBlock)), dim3(kBlock), 0, st, mv, n, d_ps0);
     const int pc = radix_sort_pairs<uint32_t>(d_ps0, d_pv0, d_ps1, d_pv1, P, 0, bit_length(n), d_radix_tmp, st,
                                               nullptr);
