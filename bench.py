@@ -203,7 +203,7 @@ def main():
                        "radix_launches_per_step": radix_launches // max(args.steps, 1),
                        "id_gather": ("%s gather to rank 0" % ("rccl" if backend == "nccl" else backend)) if distributed
                        else "none (single GPU)"},
-            "roofline": {"bound": "hbm", "kernel": "radix_scatter_kernel<uint64, 20> (full-size tiles; the round-0 suffix sort)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "radix_scatter_kernel<uint64, 24> (full-size tiles; the round-0 suffix sort)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 4),
                          "algorithmic_bytes_per_launch": int(avg_launch_bytes)},

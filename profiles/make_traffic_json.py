@@ -14,8 +14,9 @@ import os
 import sys
 
 base, tag = sys.argv[1], sys.argv[2]
-KEY = "radix_scatter_kernel<unsigned long, 20>"
-HIST = "radix_hist_kernel<unsigned long, 20>"
+ITEMS = 24  # WP_RADIX_ITEMS64
+KEY = "radix_scatter_kernel<unsigned long, %d>" % ITEMS
+HIST = "radix_hist_kernel<unsigned long, %d>" % ITEMS
 
 
 def per_kernel(counter):
@@ -38,15 +39,15 @@ hist = [k for k in ft if HIST in k][0]
 # bench.py --steps 1 --warmup 1 encodes twice (+ once more for the oracle sample check): per-launch
 # averages do not depend on the number of steps
 launches = fc[name]
-# hist kernel: one workgroup (256 threads) per tile of 20*256 keys -> keys = grid/256*5120 (upper bound)
-hist_known = sum(g / 256 * 5120 * 8 for g in fg[hist])
+# hist kernel: one workgroup (256 threads) per tile of ITEMS*256 keys (upper bound: the last tile is partial)
+hist_known = sum(g / 256 * (ITEMS * 256) * 8 for g in fg[hist])
 factor = hist_known / ft[hist]
 fetch = 2.0 * ft[name] / launches
 write = wt[name] / wc[name]
 bench = json.load(open(os.path.join(base, "%s_bench.json" % tag)))
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 out = {
-    "kernel": "radix_scatter_kernel<uint64, 20>",
+    "kernel": "radix_scatter_kernel<uint64, %d>" % ITEMS,
     "round": tag,
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 "
               "--warmup 1 --no-cpu-baseline` (profiles/collect.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md "

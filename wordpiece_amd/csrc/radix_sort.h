@@ -31,12 +31,12 @@ constexpr int kBinsPerThread = kRadixBins / kBlock;
 template <typename KeyT>
 struct RadixCfg {
 #ifndef WP_RADIX_ITEMS64
-#define WP_RADIX_ITEMS64 20
+#define WP_RADIX_ITEMS64 24  // 6144-key tiles: 74 KB of LDS staging, two workgroups per CU (16 / 20 / 24: 13.78 / 13.73 / 13.69 ms)
 #endif
   static constexpr int kItems = sizeof(KeyT) == 8 ? WP_RADIX_ITEMS64 : 16;
   static constexpr int kTile = kBlock * kItems;
   // Inputs of up to kSmallN elements (mark / step lists, the large groups of a doubling round) use
-  // tiles of kSmallItems per thread: a 5120-key tile takes ~70 us from first load to last store, and
+  // tiles of kSmallItems per thread: a full-size tile takes ~70 us from first load to last store, and
   // with less than one tile per CU that latency is the whole pass.
   static constexpr int kSmallItems = 4;
   static constexpr int kSmallTile = kBlock * kSmallItems;
