@@ -471,14 +471,13 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   // workgroup (and of its neighbours on the same XCD) fall into one ~1/256 window of the rank table
   // and merge in that XCD's L2 (measured: 2.1 ms -> 1.0 ms for 1e8 stores).  t_dst/t_val: scratch.
   static const int bin_bits = getenv("WP_BIN_BITS") ? atoi(getenv("WP_BIN_BITS")) : 8;
-  static const int sp_lds = getenv("WP_SP_LDS") ? atoi(getenv("WP_SP_LDS")) : 0;  // occupancy experiment
   auto store_ranks = [&](uint32_t *dst, uint32_t *val, uint32_t *t_dst, uint32_t *t_val, size_t m) {
     if (bin_bits > 0 && m >= (1u << 22)) {
       const int hb = bit_length(n - 1);
       // (the top bits of a text position are uniformly distributed: histogram by LDS atomics)
       const int bc = radix_sort_pairs<uint32_t>(dst, val, t_dst, t_val, m, std::max(0, hb - bin_bits), hb, d_radix_tmp,
                                                 st, nullptr, false, hb + 1);
-      hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), sp_lds, st, bc ? t_dst : dst,
+      hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, bc ? t_dst : dst,
                          bc ? t_val : val, m, d_rank, 1);
     } else {
       hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, dst, val, m, d_rank, 0);
