@@ -59,7 +59,9 @@ int wp_linear_encode(wp_vocab *v, const char *utf8, size_t nbytes, int32_t **ids
 
 /* Same path with the text already resident in device memory and the ids left
  * there (what bench.py times; what a training input pipeline would consume).
- * `d_ids` is owned by the handle and valid until the next call on it. */
+ * `d_ids` is owned by the handle and valid until the next call on it.
+ * `d_utf8` must be 4-byte aligned and readable up to the next multiple of 16 bytes behind
+ * `nbytes` (the decoder loads whole words; the padding bytes are ignored). */
 int wp_linear_encode_device(wp_vocab *v, const void *d_utf8, size_t nbytes,
                             const int32_t **d_ids, size_t *n_ids);
 
