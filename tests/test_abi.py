@@ -71,3 +71,20 @@ def test_shard_bounds_cut_at_whitespace():
         for (s0, e0), (s1, e1) in zip(b, b[1:]):
             assert e0 == s1
             assert e0 == len(data) or data[e0] in b" \t\n"
+
+
+def test_file_entry_points_report_missing_files(tmp_path):
+    """linear.cpp:337-374: a missing text file throws (Boost's mapped_file there, mmap here); a missing
+    vocab file is an empty vocabulary (std::ifstream reads nothing, utils.cpp:123-137) and an output
+    file that cannot be created is an error.  All before the device is needed."""
+    vf = tmp_path / "v.txt"
+    vf.write_text("a\nb\n")
+    with pytest.raises(W.WordPieceError, match="cannot open"):
+        W.linear.encode(str(tmp_path / "missing.txt"), str(vf))
+    with pytest.raises(W.WordPieceError, match="cannot open"):
+        W.linear.encodeExternal(str(vf), str(vf), str(tmp_path / "no_such_dir" / "out.txt"), 1000)
+    with pytest.raises(W.WordPieceError, match="memory_limit too small"):
+        W.linear.encodeExternal(str(vf), str(vf), str(tmp_path / "out.txt"), 10)
+    empty = tmp_path / "empty.txt"
+    empty.write_bytes(b"")
+    assert W.linear.encode(str(empty), str(tmp_path / "missing_vocab.txt")) == []  # nothing to encode, nothing loaded
