@@ -65,6 +65,20 @@ int wp_linear_encode(wp_vocab *v, const char *utf8, size_t nbytes, int32_t **ids
 int wp_linear_encode_device(wp_vocab *v, const void *d_utf8, size_t nbytes,
                             const int32_t **d_ids, size_t *n_ids);
 
+/* The same call sharded over several GPUs of the node, behind the boundary: the reference's own
+ * precedent is the in-library chunking at whitespace of linear.cpp:283-299 (thread chunks) and
+ * linear.cpp:355-367 (encodeExternal batches).  The text is cut at ASCII whitespace into one shard
+ * per entry of `devices` (HIP ordinals; an ordinal may repeat), balanced by code points; every
+ * shard is encoded on its device by its own host thread against the replicated vocabulary, and the
+ * ids are downloaded in shard order into one host buffer (free with wp_free).
+ * devices == NULL: the first n_devices visible GPUs (n_devices <= 0: all of them). */
+int wp_linear_encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const int *devices,
+                           int n_devices, int32_t **ids, size_t *n_ids);
+
+/* Sizes the handle's device arenas and host staging for inputs of up to `nbytes`, so that the
+ * first encode does not pay for the allocations (about 100 bytes of HBM per input symbol). */
+int wp_reserve(wp_vocab *v, size_t nbytes);
+
 /* replaces word_piece::linear::encode(text_file, vocab_file)   word_piece.hpp:14, linear.cpp:337-341 */
 int wp_linear_encode_file(const char *text_file, const char *vocab_file, int32_t **ids,
                           size_t *n_ids);
@@ -92,6 +106,14 @@ int wp_linear_encode_external(const char *text_file, const char *vocab_file, con
                                  and some spacing char occurs inside a multi-char token, e.g. CJK
                                  text with multi-char CJK tokens; long words of ordinary
                                  vocabularies are walked by pointer doubling instead) */
+#define WP_OPT_ARENA_GUARD 8  /* 1: debugging aid — every device arena allocation is followed by a
+                                 guard zone that is checked after the encode; a kernel that wrote
+                                 outside its buffer makes the call fail with WP_ERR_HIP
+                                 (env WP_ARENA_GUARD=1 switches it on for every handle) */
+#define WP_OPT_DEVICES 9      /* number of GPUs wp_linear_encode (and with it word_piece::linear::encode)
+                                 shards a host buffer over, as wp_linear_encode_multi does:
+                                 1 (default) = the handle's device only, -1 = all visible GPUs.
+                                 Env WP_DEVICES=<count>|all sets the default for new handles. */
 int wp_set_option(wp_vocab *v, int option, int64_t value);
 
 /* ---- statistics of the last encode on this handle (for bench.py / roofline) ---- */
@@ -108,6 +130,20 @@ typedef struct {
                                  2: class rule + long words by pointer doubling          */
   double ms_h2d, ms_d2h;      /* wp_linear_encode only: host time of the text upload (with
                                  WP_OPT_STAGE_TIMING) and of the id download                */
+  int64_t radix_digit_bytes;  /* digit bytes written next to the records by the radix scatter
+                                 launches (1 per element and launch, read back by the next
+                                 histogram instead of the 8-byte key)                       */
+  double ms_host_total;       /* host entry points: wall time of the whole call (upload, device
+                                 path, download)                                            */
+  int32_t guard_zones;        /* WP_OPT_ARENA_GUARD: guard zones checked (all intact, or the call
+                                 fails)                                                     */
+  int32_t n_devices;          /* devices that took part (wp_linear_encode_multi), else 1    */
+  int32_t vocab_in_s;         /* 1: S = text . 1 . vocab as in linear.cpp:77-101; 0: S = text . 1 and
+                                 the vocab comes in through the per-handle vocab structure  */
+  int32_t reserved0;
+  int64_t needed_after_round0; /* depth-capped mode: suffixes in tied groups that carry the key of an
+                                 eligible token longer than the key — the only ones that go on to
+                                 round 1 (-1: every tied group does, e.g. full depth)          */
 } wp_stats;
 int wp_get_stats(const wp_vocab *v, wp_stats *out);
 

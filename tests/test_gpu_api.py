@@ -130,3 +130,88 @@ def test_encode_tensor_on_device(corpus):
     view = gv.encode_tensor(t, copy=False)
     assert np.array_equal(view.cpu().numpy(), exp)
     assert gv.encode_tensor(torch.zeros(0, dtype=torch.uint8, device="cuda")).numel() == 0
+
+
+def test_encode_multi_same_gpu_contexts(corpus):
+    """wp_linear_encode_multi: the sharded path behind the C ABI (one host thread + context per entry of
+    the device list, whitespace cuts balanced by code points, ids downloaded in shard order).  Several
+    contexts on the one GPU of this box exercise everything but the second device."""
+    _, _, text, vocab, _ = corpus
+    exp = O.Vocab(vocab).encode(text)
+    gv = W.Vocab(vocab)
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        ids = gv.encode_multi(text, devs)
+        assert np.array_equal(ids, exp), devs
+        st = gv.stats()
+        assert st["n_devices"] == len(devs) and st["n_bytes"] == len(text) and st["n_ids"] == len(exp)
+    assert np.array_equal(gv.encode_multi(text, None), exp)       # all visible GPUs
+    assert len(gv.encode_multi(b"", [0, 0])) == 0
+    assert np.array_equal(gv.encode_multi(b"ab", [0, 0, 0]), O.Vocab(vocab).encode(b"ab"))  # empty shards
+    # mixed scripts: the cut positions follow the code points, not the bytes
+    mixed = ("привет мир " * 40000).encode() + text[:400_000] + ("中文 分词 " * 30000).encode()
+    assert np.array_equal(gv.encode_multi(mixed, [0, 0]), O.Vocab(vocab).encode(mixed))
+    # WP_OPT_DEVICES routes the plain host entry point (and word_piece::linear::encode) through the same path
+    gv.set_option(W.WP_OPT_DEVICES, -1)
+    big = text + b" " + text
+    assert np.array_equal(gv.encode(big), O.Vocab(vocab).encode(big))
+    with pytest.raises(W.WordPieceError, match="no such HIP device"):
+        gv.encode_multi(text, [0, 99])
+
+
+def test_reserve_and_pinned_id_blocks(corpus):
+    """wp_reserve pre-sizes the arenas; the id buffers come from a pool of pinned blocks that wp_free
+    feeds (a block is reused by the next call once its numpy view is gone)."""
+    _, _, text, vocab, _ = corpus
+    gv = W.Vocab(vocab)
+    gv.reserve(len(text))
+    exp = O.Vocab(vocab).encode(text)
+    seen = set()
+    for _ in range(6):  # (blocks go back to the pool when their numpy view dies: a handful of addresses at most)
+        a = gv.encode(text)
+        seen.add(a.ctypes.data)
+        assert np.array_equal(a, exp)
+        del a
+    assert len(seen) <= 4
+    assert gv.stats()["ms_host_total"] > 0
+
+
+def test_arena_guard_zones_intact(corpus):
+    """WP_OPT_ARENA_GUARD: a guard zone behind every arena allocation, checked after the encode — no
+    kernel of the path writes outside the buffer it was given (small- and full-tile radix
+    configurations, large-group path, coverage anchors, long words)."""
+    _, _, text, vocab, _ = corpus
+    cases = [(text, vocab)]
+    cases.append(synth.deep_prefix_corpus(3_000_000, seed=5))          # large groups: side-stream radix sorts
+    cases.append(synth.multilingual_corpus(3_000_000, seed=6, vocab_size=6000))  # wide symbols, coverage anchors
+    cases.append((b"ab " * 5 + b"x" * 300_000 + b" ab", ["a", "##b", "x", "##x"]))  # long word
+    for t, vc in cases:
+        for full in (0, 1):
+            gv = W.Vocab(vc)
+            gv.set_option(W.WP_OPT_ARENA_GUARD, 1)
+            gv.set_option(W.WP_OPT_FULL_DEPTH, full)
+            ids = gv.encode(t)
+            assert gv.stats()["guard_zones"] > 50
+            if len(t) <= 3_100_000 and full == 0:
+                assert np.array_equal(ids, O.Vocab(vc).encode(t))
+
+
+def test_symbol_limit_is_on_code_points():
+    """linear.cpp:104-106 limits total_length (code points + vocab symbols), not bytes: 2.1 GB of ASCII is
+    "64bit not implemented"; 2.1 GB of three-byte characters (0.7e9 code points) is encoded."""
+    vocab = ["ab", "##c", "中", "文", "[UNK]"]
+    gv = W.Vocab(vocab)
+    unit = b"abc abd " * 1024
+    big = unit * (2_100_000_000 // len(unit) + 1)
+    with pytest.raises(W.WordPieceError, match="64bit not implemented"):
+        gv.encode(big)
+    del big
+    unit = "中文 中 文x ".encode() * 1024
+    reps = 2_100_000_000 // len(unit) + 1
+    big = unit * reps
+    assert len(big) > 2_000_000_000
+    ids = gv.encode(big)
+    one = gv.encode(unit)
+    assert np.array_equal(one, O.Vocab(vocab).encode(unit))
+    assert len(ids) == len(one) * reps
+    assert np.array_equal(ids[:len(one)], one) and np.array_equal(ids[-len(one):], one)
+    assert np.array_equal(ids.reshape(reps, len(one)), np.broadcast_to(one, (reps, len(one))))

@@ -420,5 +420,6 @@ def test_deep_prefix_24mb_ids():
     gv = W.Vocab(vocab)
     ids = gv.encode(text)
     st = gv.stats()
-    assert st["longest_token"] == 512 and st["sorted_depth"] > 512
+    # (the groups that carry a long token's key are refined until their depth exceeds the longest token)
+    assert st["longest_token"] == 512 and st["rounds"] >= 7 and 0 < st["needed_after_round0"] < st["n_total"] // 50
     assert np.array_equal(ids, _oracle_ids_fast(text, vocab))

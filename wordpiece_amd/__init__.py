@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WP_LIB") or os.path.join(_HERE, "libwordpiece_amd.so")
 
 WP_OPT_FULL_DEPTH, WP_OPT_DEVICE, WP_OPT_KEEP_DEBUG, WP_OPT_STAGE_TIMING, WP_OPT_LCP_KASAI = 1, 2, 3, 4, 5
-WP_OPT_FUSED_RERANK, WP_OPT_COVER_ANCHORS = 6, 7
+WP_OPT_FUSED_RERANK, WP_OPT_COVER_ANCHORS, WP_OPT_ARENA_GUARD, WP_OPT_DEVICES = 6, 7, 8, 9
 
 # every symbol include/wordpiece_amd.h declares (checked by the CPU test-suite)
 ABI_SYMBOLS = [
@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "wp_vocab_unk_id", "wp_vocab_token_flags", "wp_vocab_token_len", "wp_linear_encode",
     "wp_linear_encode_device", "wp_linear_encode_file", "wp_linear_encode_external", "wp_set_option",
     "wp_get_stats", "wp_linear_debug_fetch", "wp_free", "wp_last_error", "wp_device_count",
+    "wp_linear_encode_multi", "wp_reserve",
 ]
 
 
@@ -45,7 +46,10 @@ class Stats(C.Structure):
                 ("active_per_round", C.c_int64 * 40),
                 ("ms_total", C.c_double), ("ms_decode", C.c_double), ("ms_sa", C.c_double), ("ms_lcp", C.c_double),
                 ("ms_scan", C.c_double), ("ms_walk", C.c_double), ("ms_radix_scatter", C.c_double),
-                ("n_anchors", C.c_int64), ("anchor_mode", C.c_int32), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double)]
+                ("n_anchors", C.c_int64), ("anchor_mode", C.c_int32), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double),
+                ("radix_digit_bytes", C.c_int64), ("ms_host_total", C.c_double), ("guard_zones", C.c_int32),
+                ("n_devices", C.c_int32), ("vocab_in_s", C.c_int32), ("reserved0", C.c_int32),
+                ("needed_after_round0", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "active_per_round"}
@@ -79,6 +83,9 @@ def lib():
         L.wp_vocab_token_len.restype = C.c_int64
         L.wp_linear_encode.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32p), C.POINTER(C.c_size_t)]
         L.wp_linear_encode_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.wp_linear_encode_multi.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.POINTER(i32p),
+                                             C.POINTER(C.c_size_t)]
+        L.wp_reserve.argtypes = [vp, C.c_size_t]
         L.wp_linear_encode_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(i32p), C.POINTER(C.c_size_t)]
         L.wp_linear_encode_external.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
         L.wp_set_option.argtypes = [vp, C.c_int, C.c_int64]
@@ -151,6 +158,25 @@ class Vocab:
         n = C.c_size_t()
         _check(lib().wp_linear_encode(self._h, b, len(b), C.byref(ids), C.byref(n)))
         return _adopt_ids(ids, n.value)
+
+    def encode_multi(self, text, devices=None):
+        """Host bytes -> numpy int32 ids, sharded over several GPUs behind the C ABI
+        (wp_linear_encode_multi).  devices: list of HIP ordinals (may repeat), an int (the first k
+        visible GPUs) or None (all visible GPUs)."""
+        b = _bytes(text)
+        ids = C.POINTER(C.c_int32)()
+        n = C.c_size_t()
+        if isinstance(devices, (list, tuple)):
+            arr = (C.c_int * len(devices))(*devices)
+            rc = lib().wp_linear_encode_multi(self._h, b, len(b), arr, len(devices), C.byref(ids), C.byref(n))
+        else:
+            rc = lib().wp_linear_encode_multi(self._h, b, len(b), None, int(devices or 0), C.byref(ids), C.byref(n))
+        _check(rc)
+        return _adopt_ids(ids, n.value)
+
+    def reserve(self, nbytes):
+        """Pre-sizes the device arenas and host staging for inputs of up to nbytes (wp_reserve)."""
+        _check(lib().wp_reserve(self._h, int(nbytes)))
 
     def encode_device(self, d_ptr, nbytes):
         """Text already in HBM at `d_ptr` -> (device pointer of int32 ids, count).  The id buffer is

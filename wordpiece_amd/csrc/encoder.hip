@@ -15,6 +15,9 @@
 #include <fstream>
 #include <future>
 #include <memory>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/wordpiece_amd.h"
@@ -22,6 +25,7 @@
 #include "decode.h"
 #include "format.h"
 #include "local_sort.h"
+#include "prune.h"
 #include "radix_sort.h"
 #include "scanline.h"
 #include "suffix_array.h"
@@ -51,24 +55,72 @@ struct DeviceBuffer {
   }
 };
 
+// Guard zones (WP_OPT_ARENA_GUARD / env WP_ARENA_GUARD=1, a debugging aid): every arena allocation is
+// followed by kGuardBytes of a fixed pattern; after the encode a kernel checks that every zone is
+// intact, i.e. that no kernel wrote past the end (or before the start) of the buffer it was given.
+constexpr size_t kGuardBytes = 256;
+constexpr uint32_t kGuardWord = 0xA5C3F00Du;
+
+__global__ __launch_bounds__(kBlock) void guard_fill_kernel(char *base, const unsigned long long *offs, int count) {
+  const int z = blockIdx.x;
+  if (z >= count) return;
+  uint32_t *g = reinterpret_cast<uint32_t *>(base + offs[z]);
+  if (threadIdx.x < kGuardBytes / 4) g[threadIdx.x] = kGuardWord;
+}
+// bad[0] = number of damaged zones, bad[1] = 1 + index of the first one
+__global__ __launch_bounds__(kBlock) void guard_check_kernel(const char *base, const unsigned long long *offs, int count,
+                                                             uint32_t *bad) {
+  const int z = blockIdx.x;
+  if (z >= count) return;
+  const uint32_t *g = reinterpret_cast<const uint32_t *>(base + offs[z]);
+  const bool broken = threadIdx.x < kGuardBytes / 4 && g[threadIdx.x] != kGuardWord;
+  if (__syncthreads_or(broken) && threadIdx.x == 0) {
+    atomicAdd(&bad[0], 1u);
+    atomicMin(&bad[1], static_cast<uint32_t>(z) + 1u);
+  }
+}
+
 // bump allocator over a DeviceBuffer: plan() first with the same sequence of take() calls
 struct Arena {
   DeviceBuffer *buf;
   size_t off = 0;
-  bool planning = true;
-  explicit Arena(DeviceBuffer *b) : buf(b) {}
+  bool planning = true, guard = false;
+  std::vector<unsigned long long> zones;  // byte offsets of the guard zones (guard mode)
+  explicit Arena(DeviceBuffer *b, bool g = false) : buf(b), guard(g) {}
   template <typename T>
   T *take(size_t count) {
     size_t bytes = (count * sizeof(T) + 255) & ~static_cast<size_t>(255);
     size_t o = off;
     off += bytes;
+    if (guard) {
+      if (!planning) zones.push_back(off);
+      off += kGuardBytes;
+    }
     if (planning) return nullptr;
     return reinterpret_cast<T *>(static_cast<char *>(buf->p) + o);
   }
   void commit() {
-    buf->ensure(off);
+    buf->ensure(off + (guard ? 8 * 512 : 0));  // (guard mode: room for the zone table behind the arena)
     off = 0;
     planning = false;
+  }
+  // the zone table lives behind the last allocation; call after the second (real) round of take()s
+  unsigned long long *zone_table() const {
+    return reinterpret_cast<unsigned long long *>(static_cast<char *>(buf->p) + ((off + 255) & ~static_cast<size_t>(255)));
+  }
+  void arm(hipStream_t st) {
+    if (!guard || zones.empty()) return;
+    if (zones.size() > 500) throw std::logic_error("arena guard: too many allocations");
+    WP_HIP(hipMemcpyAsync(zone_table(), zones.data(), zones.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    WP_HIP(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(guard_fill_kernel, dim3(zones.size()), dim3(kBlock), 0, st, static_cast<char *>(buf->p), zone_table(),
+                       static_cast<int>(zones.size()));
+  }
+  // bad: 2 device words, cleared by the caller to {0, 0xffffffff}
+  void check(hipStream_t st, uint32_t *bad) const {
+    if (!guard || zones.empty()) return;
+    hipLaunchKernelGGL(guard_check_kernel, dim3(zones.size()), dim3(kBlock), 0, st, static_cast<const char *>(buf->p),
+                       zone_table(), static_cast<int>(zones.size()), bad);
   }
 };
 
@@ -81,6 +133,8 @@ static int bit_length(uint64_t v) {
   return b;
 }
 
+constexpr int kScalars = 32;
+
 struct Context {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -91,7 +145,7 @@ struct Context {
   int32_t *d_elig_id = nullptr, *d_tok_len = nullptr;
   DeviceBuffer text_buf, a_buf, b_buf, fmt_buf;  // fmt_buf: id text of encodeExternal
   uint32_t *d_used = nullptr, *d_lut = nullptr, *d_scan_tmp = nullptr;  // code point tables
-  uint32_t *d_scalars = nullptr;                                         // 16 words of device scalars
+  uint32_t *d_scalars = nullptr;                                         // kScalars words of device scalars
   uint8_t *d_code = nullptr;     // symbol code tables: cw u16[256] | len u8[256] | bmask u16[4096]
   uint32_t *d_symhist = nullptr;  // 256 counters
   uint32_t *h_scalars = nullptr;                                         // pinned mirror
@@ -117,9 +171,12 @@ using namespace wp;
 
 struct wp_vocab {
   HostVocab hv;
-  std::unique_ptr<Context> ctx;
+  std::unique_ptr<Context> ctx;                  // the handle's own device context
+  std::vector<std::unique_ptr<Context>> multi;  // one per entry of the device list of wp_linear_encode_multi
   int device = -1;
   bool full_depth = false, keep_debug = false, stage_timing = false, lcp_kasai = false, fused_rerank = false, cover_anchors = false;
+  bool arena_guard = false;
+  int n_devices = 1;  // WP_OPT_DEVICES: GPUs wp_linear_encode shards a host buffer over (-1: all visible)
   wp_stats stats{};
   ~wp_vocab();
 };
@@ -160,18 +217,16 @@ static T *upload(const std::vector<T> &v, hipStream_t st) {
   return d;
 }
 
-static Context *get_context(wp_vocab *v) {
-  if (v->ctx) {
-    WP_HIP(hipSetDevice(v->ctx->device));
-    return v->ctx.get();
-  }
+// a fresh context (streams, vocab tables, scratch) on `device` (< 0: the calling thread's current device)
+static std::unique_ptr<Context> make_context(const wp_vocab *v, int device) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
     throw HipError("no HIP device available: the Linear WordPiece path has no CPU fallback");
   }
   std::unique_ptr<Context> c(new Context());
-  if (v->device >= 0) {
-    c->device = v->device;
+  if (device >= 0) {
+    if (device >= count) throw std::invalid_argument("no such HIP device: " + std::to_string(device));
+    c->device = device;
   } else {
     WP_HIP(hipGetDevice(&c->device));
   }
@@ -189,13 +244,18 @@ static Context *get_context(wp_vocab *v) {
   WP_HIP(hipMalloc(&c->d_used, sizeof(uint32_t) * kCpTableSize));
   WP_HIP(hipMalloc(&c->d_lut, sizeof(uint32_t) * kCpTableSize));
   WP_HIP(hipMalloc(&c->d_scan_tmp, sizeof(uint32_t) * (cdiv(kCpTableSize, kScanTile) + 8)));
-  WP_HIP(hipMalloc(&c->d_scalars, sizeof(uint32_t) * 16));
+  WP_HIP(hipMalloc(&c->d_scalars, sizeof(uint32_t) * kScalars));
   WP_HIP(hipMalloc(&c->d_code, 512 + 256 + kDecodeTableBytes));
   WP_HIP(hipMalloc(&c->d_symhist, sizeof(uint32_t) * 256));
-  WP_HIP(hipHostMalloc(&c->h_scalars, sizeof(uint32_t) * 16));
+  WP_HIP(hipHostMalloc(&c->h_scalars, sizeof(uint32_t) * kScalars));
   for (auto &e : c->ev) WP_HIP(hipEventCreate(&e));
   WP_HIP(hipStreamSynchronize(c->stream));
-  v->ctx = std::move(c);
+  return c;
+}
+
+static Context *get_context(wp_vocab *v) {
+  if (!v->ctx) v->ctx = make_context(v, v->device);
+  WP_HIP(hipSetDevice(v->ctx->device));
   return v->ctx.get();
 }
 
@@ -206,16 +266,21 @@ static void fetch_scalars(Context *c, int count) {
 }
 
 template <typename SymT>
-static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t *d_text, size_t nbytes,
-                              const uint32_t *d_tile_prefix, size_t n_text, size_t n, uint32_t *d_cps, uint8_t *d_cls,
-                              int bits, size_t *n_ids_out);
+static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena &ar, Arena &aa, const uint8_t *d_text,
+                              size_t nbytes, const uint32_t *d_tile_prefix, size_t n_text, size_t n, uint32_t *d_cps,
+                              uint8_t *d_cls, int bits, size_t *n_ids_out);
 
-// The whole device path.  d_text must be 4-byte aligned and readable up to the next multiple of 4.
-static void encode_on_device(wp_vocab *v, const uint8_t *d_text, size_t nbytes, size_t *n_ids_out) {
-  Context *c = get_context(v);
+static bool env_flag(const char *name) {
+  const char *e = getenv(name);
+  return e && atoi(e) != 0;
+}
+
+// The whole device path on context c (the calling thread has c's device current).  d_text must be
+// 4-byte aligned and readable up to the next multiple of 16.  S: statistics of this call.
+static void encode_on_device(const wp_vocab *v, Context *c, const uint8_t *d_text, size_t nbytes, size_t *n_ids_out,
+                             wp_stats &S) {
   hipStream_t st = c->stream;
   const HostVocab &hv = v->hv;
-  wp_stats &S = v->stats;
   std::memset(&S, 0, sizeof(S));
   S.n_bytes = static_cast<int64_t>(nbytes);
   S.longest_token = hv.longest;
@@ -223,17 +288,22 @@ static void encode_on_device(wp_vocab *v, const uint8_t *d_text, size_t nbytes, 
   c->dbg = {};
   *n_ids_out = 0;
   if (nbytes == 0) return;  // linear.cpp:323-325
-  if (nbytes > 2000000000ull) throw std::length_error("64bit not implemented");
+  // (no limit on the byte length: the reference limits total_length = code points + vocab symbols,
+  // linear.cpp:104-106, checked below once the code points are counted — in 64 bits, since the tile
+  // prefix itself is 32-bit and wraps for inputs beyond 4 G code points)
+  static const bool env_guard = env_flag("WP_ARENA_GUARD");
+  const bool guard = v->arena_guard || env_guard;
 
   c->rstats.passes = 0;
   c->rstats.elems = 0;
+  c->rstats.digit_bytes = 0;
   c->rstats.spans.on = v->stage_timing;
   c->rstats.spans.used = 0;
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[0], st));
 
   // ---------------- phase A: decode ----------------
   const unsigned dec_tiles = cdiv(nbytes, kDecTile);
-  Arena aa(&c->a_buf);
+  Arena aa(&c->a_buf, guard);
   uint32_t *d_tile_cnt = nullptr, *d_cnt_tmp = nullptr, *d_cps = nullptr;
   uint8_t *d_cls = nullptr;
   for (int pass = 0; pass < 2; pass++) {
@@ -243,16 +313,21 @@ static void encode_on_device(wp_vocab *v, const uint8_t *d_text, size_t nbytes, 
     d_cls = aa.take<uint8_t>(nbytes + 1);
     if (pass == 0) aa.commit();
   }
-  WP_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(uint32_t) * 16, st));
+  aa.arm(st);
+  WP_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(uint32_t) * kScalars, st));
   WP_HIP(hipMemsetAsync(c->d_used, 0, sizeof(uint32_t) * kCpTableSize, st));
   hipLaunchKernelGGL(decode_count_kernel, dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes, d_tile_cnt,
                      reinterpret_cast<unsigned long long *>(c->d_scalars + 2), c->d_used);
-  device_exclusive_scan(d_tile_cnt, d_tile_cnt, dec_tiles, d_cnt_tmp, c->d_scalars + 0, st);
+  device_exclusive_scan(d_tile_cnt, d_tile_cnt, dec_tiles, d_cnt_tmp, c->d_scalars + 0, st, nullptr,
+                        reinterpret_cast<unsigned long long *>(c->d_scalars + 14));
   hipLaunchKernelGGL(mark_used_kernel, dim3(cdiv(std::max<size_t>(hv.stream.size(), 1), kBlock)), dim3(kBlock), 0,
                      st, c->d_stream, hv.stream.size(), c->d_used);
   device_exclusive_scan(c->d_used, c->d_lut, kCpTableSize, c->d_scan_tmp, c->d_scalars + 1, st);
   WP_LAUNCH_CHECK();
-  fetch_scalars(c, 4);
+  fetch_scalars(c, 16);
+  unsigned long long n_text64;
+  std::memcpy(&n_text64, c->h_scalars + 14, sizeof(n_text64));
+  if (n_text64 + 1 + hv.stream.size() > 2000000000ull) throw std::length_error("64bit not implemented");  // linear.cpp:104-106
   const size_t n_text = c->h_scalars[0];
   const uint32_t sigma = c->h_scalars[1];
   unsigned long long dropped;
@@ -267,18 +342,18 @@ static void encode_on_device(wp_vocab *v, const uint8_t *d_text, size_t nbytes, 
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[1], st));
 
   const int bits = std::max(1, bit_length(sigma));  // symbols are 1..sigma, 0 = past the end
-  Arena ab(&c->b_buf);
+  Arena ab(&c->b_buf, guard);
   if (sigma <= 255) {
-    run_sa_and_beyond<uint8_t>(v, c, ab, d_text, nbytes, d_tile_cnt, n_text, n, d_cps, d_cls, bits, n_ids_out);
+    run_sa_and_beyond<uint8_t>(v, c, S, ab, aa, d_text, nbytes, d_tile_cnt, n_text, n, d_cps, d_cls, bits, n_ids_out);
   } else {
-    run_sa_and_beyond<uint32_t>(v, c, ab, d_text, nbytes, d_tile_cnt, n_text, n, d_cps, d_cls, bits, n_ids_out);
+    run_sa_and_beyond<uint32_t>(v, c, S, ab, aa, d_text, nbytes, d_tile_cnt, n_text, n, d_cps, d_cls, bits, n_ids_out);
   }
 }
 
 template <typename SymT>
-static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t *d_text, size_t nbytes,
-                              const uint32_t *d_tile_prefix, size_t n_text, size_t n, uint32_t *d_cps, uint8_t *d_cls,
-                              int bits, size_t *n_ids_out) {
+static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena &ar, Arena &aa, const uint8_t *d_text,
+                              size_t nbytes, const uint32_t *d_tile_prefix, size_t n_text, size_t n, uint32_t *d_cps,
+                              uint8_t *d_cls, int bits, size_t *n_ids_out) {
   hipStream_t st = c->stream;
   hipStream_t st2 = c->stream2;
   // st2 starts after everything queued on st so far / st continues after everything queued on st2
@@ -291,7 +366,6 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     WP_HIP(hipStreamWaitEvent(st, c->evs[1], 0));
   };
   const HostVocab &hv = v->hv;
-  wp_stats &S = v->stats;
   const bool full = v->full_depth || hv.n_dup_eligible > 0 || v->lcp_kasai;
   const uint32_t need_depth = static_cast<uint32_t>(std::min<int64_t>(hv.longest + 1, 0x7fffffff));
   S.symbol_bits = bits;
@@ -307,7 +381,14 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   const size_t radix_words = std::max(radix_tmp_words<uint64_t>(n), radix_tmp_words<uint32_t>(std::max<size_t>(n, kStepsPerMark * std::max(M, 1) + 1)));
   const size_t emit_tiles = cdiv(std::max<size_t>(n_text, 1), kScanTile);
 
+  // digit bytes (radix_sort.h): the round-0 sort's histograms read 1 byte per key instead of 8
+  static const bool env_no_digit_bytes = env_flag("WP_NO_DIGIT_BYTES");
+  const bool use_digit_bytes = !env_no_digit_bytes && kRadixBits <= 8 && n > kRadixSmallN;
   SymT *d_sym = nullptr;
+  uint8_t *DG0 = nullptr, *DG1 = nullptr, *d_need = nullptr;
+  uint32_t *d_claim = nullptr;
+  size_t claim_size = 1024;  // hash table of claimed key ranges (prune.h): a power of two >= 2 M
+  while (claim_size < 2 * static_cast<size_t>(std::max(M, 1))) claim_size *= 2;
   uint64_t *K0 = nullptr, *K1 = nullptr;
   RankEntry *d_rank = nullptr;
   uint32_t *AD0 = nullptr, *AD1 = nullptr, *d_tdep = nullptr, *d_gdepth = nullptr, *d_anchors = nullptr,
@@ -332,6 +413,10 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     d_sym = ar.take<SymT>(n + 16);
     K0 = ar.take<uint64_t>(n);
     K1 = ar.take<uint64_t>(n);
+    DG0 = use_digit_bytes ? ar.take<uint8_t>(n + 64) : nullptr;
+    DG1 = use_digit_bytes ? ar.take<uint8_t>(n + 64) : nullptr;
+    d_need = ar.take<uint8_t>(n + 64);
+    d_claim = ar.take<uint32_t>(claim_size);
     V0 = ar.take<uint32_t>(n);
     V1 = ar.take<uint32_t>(n);
     AS0 = ar.take<uint32_t>(n);
@@ -387,6 +472,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     d_emit_tmp = ar.take<uint32_t>(cdiv(emit_tiles, kScanTile) + 8);
     if (pass == 0) ar.commit();
   }
+  ar.arm(st);
 
   // side stream: the anchor list and the cleared emit array only need the class bytes
   auto launch_anchors = [&](bool do_fork) {
@@ -446,12 +532,15 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   }
   S.symbols_per_key = static_cast<int32_t>(kKeyBits / std::max(1.0, code.avg_bits));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(build_keys0_kernel<SymT>), dim3(cdiv(n, kKeyTile)), dim3(kBlock), 0, st, d_sym,
-                     n, dcode, K0);
+                     n, dcode, K0, DG0);
   WP_LAUNCH_CHECK();
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[2], st));
 
   // ---------------- suffix array by prefix doubling ----------------
-  const DepthRule rule{need_depth, full ? 1 : 0};
+  // round 0 only keeps the tied groups that carry the key of a long eligible token (prune.h)
+  static const bool env_no_prune = env_flag("WP_NO_PRUNE");
+  const bool prune = !full && !env_no_prune && M > 0;
+  DepthRule rule{need_depth, full ? 1 : 0, nullptr};
   // after every rerank: classify the new groups (large ones take the global path next round)
   // (runs on the side stream, next to the rank scatter)
   auto classify_groups = [&](size_t list_len) {
@@ -476,7 +565,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       const int hb = bit_length(n - 1);
       // (the top bits of a text position are uniformly distributed: histogram by LDS atomics)
       const int bc = radix_sort_pairs<uint32_t>(dst, val, t_dst, t_val, m, std::max(0, hb - bin_bits), hb, d_radix_tmp,
-                                                st, nullptr, false, hb + 1);
+                                                radix_words, st, nullptr, false, hb + 1);
       hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, bc ? t_dst : dst,
                          bc ? t_val : val, m, d_rank, 1);
     } else {
@@ -484,10 +573,25 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     }
   };
   // (the low bits of a round-0 key are the tail of a compressed codeword stream: near-uniform digits)
-  int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, kKeyBits, d_radix_tmp, st, &c->rstats, true,
-                                       code.uniform_bits ? 0 : 16);
+  DigitBytes db;
+  db.dg0 = DG0;
+  db.dg1 = DG1;
+  db.dg0_ready = DG0 != nullptr;
+  // histogram by LDS atomics for the digits below this bit (near-uniform digits), by match-any ballots above
+  static const int hist_atomic_bits = getenv("WP_HIST_ATOMIC_BITS") ? atoi(getenv("WP_HIST_ATOMIC_BITS")) : 16;
+  int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, kKeyBits, d_radix_tmp, radix_words, st, &c->rstats, true,
+                                       code.uniform_bits ? 0 : hist_atomic_bits, db);
   uint64_t *keys = cur ? K1 : K0;
   uint32_t *vals = cur ? V1 : V0, *other_vals = cur ? V0 : V1;
+  if (prune) {
+    WP_HIP(hipMemsetAsync(d_need, 0, n, st));
+    WP_HIP(hipMemsetAsync(d_claim, 0xff, claim_size * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(need_groups_kernel, dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)), dim3(kBlock), 0, st, keys, n,
+                       c->d_stream, c->d_elig_start, c->d_elig_info, M, c->d_lut, dcode, d_claim,
+                       static_cast<uint32_t>(claim_size - 1), d_need,
+                       reinterpret_cast<unsigned long long *>(c->d_scalars + 18));
+    rule.need_map = d_need;
+  }
   uint32_t *slots = AS0, *other_slots = AS1;
   uint32_t *adep = AD0, *other_dep = AD1;
   bool classified = false;
@@ -579,7 +683,8 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(cdiv(n_large, kLxSpan), kBlock / kWave)), dim3(kBlock), 0, st2,
                          avals, adep, d_lg_head, d_lg_off, static_cast<uint32_t>(n_large_groups), n_large, d_rank, n, rb,
                          K1, LV0, LPOS);
-      const int lc = radix_sort_pairs<uint64_t>(K1, LV0, LK1, LV1, n_large, 0, rb + lgb, d_radix_tmp, st2, &c->rstats);
+      const int lc = radix_sort_pairs<uint64_t>(K1, LV0, LK1, LV1, n_large, 0, rb + lgb, d_radix_tmp, radix_words, st2,
+                                                &c->rstats);
       hipLaunchKernelGGL(large_writeback_kernel, dim3(std::min<size_t>(cdiv(n_large, kBlock), 8192)), dim3(kBlock), 0,
                          st2, lc ? LK1 : K1, lc ? LV1 : LV0, LPOS, n_large, AG, rb, skeys, svals);
       join();
@@ -626,8 +731,14 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
   }
   (void)n_groups;
   S.rounds = rounds;
-  // every tie that is left shares at least need_depth symbols (depth-capped mode)
-  S.sorted_depth = full ? 0x7fffffff : static_cast<int32_t>(need_depth);
+  // every tie that is left shares at least this many symbols: need_depth for the groups that went through
+  // the rounds, the shortest possible key (whole codewords in kKeyBits bits) for the groups round 0 let go
+  {
+    const int max_len = code.uniform_bits ? code.uniform_bits : kMaxCodeLen + code.lo_bits;
+    const int32_t key_syms = std::max(1, kKeyBits / max_len);
+    S.sorted_depth = full ? 0x7fffffff : (prune ? std::min<int32_t>(static_cast<int32_t>(need_depth), key_syms)
+                                                 : static_cast<int32_t>(need_depth));
+  }
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[3], st));
 
   if (v->lcp_kasai) {  // alternative LCP builder: chunked Kasai exactly as linear.cpp:18-70
@@ -651,7 +762,7 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
       hipLaunchKernelGGL(mark_slots_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, c->d_elig_start, M,
                          vocab_base, d_rank, d_mslot0, d_midx0);
       int mc = radix_sort_pairs<uint32_t>(d_mslot0, d_midx0, d_mslot1, d_midx1, M, 0, bit_length(n), d_radix_tmp,
-                                          st, nullptr);
+                                          radix_words, st, nullptr);
       mslot = mc ? d_mslot1 : d_mslot0;
       midx = mc ? d_midx1 : d_midx0;
       hipLaunchKernelGGL(mark_gather_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, midx, M, c->d_elig_id,
@@ -675,8 +786,8 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     }
     if (n_text > 0 && anchor_at == 2) launch_anchors(false);
     hipLaunchKernelGGL(piece_starts_kernel, dim3(cdiv(std::max(M, 1), kBlock)), dim3(kBlock), 0, st, mv, n, d_ps0);
-    const int pc = radix_sort_pairs<uint32_t>(d_ps0, d_pv0, d_ps1, d_pv1, P, 0, bit_length(n), d_radix_tmp, st,
-                                              nullptr);
+    const int pc = radix_sort_pairs<uint32_t>(d_ps0, d_pv0, d_ps1, d_pv1, P, 0, bit_length(n), d_radix_tmp, radix_words,
+                                              st, nullptr);
     uint32_t *pstart = pc ? d_ps1 : d_ps0;
     hipLaunchKernelGGL(piece_values_kernel, dim3(cdiv(static_cast<size_t>(P) * kWave, kBlock)), dim3(kBlock), 0, st,
                        mv, pstart, P, d_pval_p, d_pval_s);
@@ -787,12 +898,30 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
     WP_LAUNCH_CHECK();
   }
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[6], st));
-  fetch_scalars(c, 10);
+  if (ar.guard) {  // debugging aid: no kernel may have written outside the buffer it was given
+    static const uint32_t init[2] = {0u, 0xffffffffu};
+    WP_HIP(hipMemcpyAsync(c->d_scalars + 16, init, sizeof(init), hipMemcpyHostToDevice, st));
+    ar.check(st, c->d_scalars + 16);
+    aa.check(st, c->d_scalars + 16);
+    fetch_scalars(c, 18);
+    if (c->h_scalars[16] != 0) {
+      throw HipError("arena guard: " + std::to_string(c->h_scalars[16]) + " guard zone(s) overwritten, first behind allocation #" +
+                     std::to_string(c->h_scalars[17] - 1));
+    }
+    S.guard_zones = static_cast<int32_t>(ar.zones.size() + aa.zones.size());
+  }
+  fetch_scalars(c, 20);
   n_ids = n_text > 0 ? c->h_scalars[9] : 0;
+  {
+    unsigned long long needed = 0;
+    std::memcpy(&needed, c->h_scalars + 18, sizeof(needed));
+    S.needed_after_round0 = prune ? static_cast<int64_t>(needed) : -1;
+  }
 
   S.n_ids = static_cast<int64_t>(n_ids);
   S.radix_passes = c->rstats.passes;
   S.radix_pass_elems = c->rstats.elems;
+  S.radix_digit_bytes = c->rstats.digit_bytes;
   if (v->stage_timing) {
     auto span = [&](int a, int b) {
       float ms = 0;
@@ -823,7 +952,10 @@ static void run_sa_and_beyond(wp_vocab *v, Context *c, Arena &ar, const uint8_t 
 
 }  // namespace wp
 
-wp_vocab::~wp_vocab() { destroy_context(ctx.get()); }
+wp_vocab::~wp_vocab() {
+  destroy_context(ctx.get());
+  for (auto &c : multi) destroy_context(c.get());
+}
 
 // ======================================================================================
 // C ABI
@@ -857,6 +989,9 @@ static int vocab_from_lines(const std::vector<std::pair<const char *, size_t>> &
     return WP_ERR_ARG;
   }
   std::unique_ptr<wp_vocab> v(new wp_vocab());
+  if (const char *e = getenv("WP_DEVICES")) {  // default of WP_OPT_DEVICES ("all" or a count): the C++ API has no handle to set it on
+    v->n_devices = std::strcmp(e, "all") == 0 ? -1 : std::max(1, atoi(e));
+  }
   std::string err = v->hv.build(lines);
   if (!err.empty()) {
     g_last_error = err;
@@ -919,6 +1054,8 @@ int wp_set_option(wp_vocab *v, int option, int64_t value) {
     case WP_OPT_LCP_KASAI: v->lcp_kasai = value != 0; return WP_OK;
     case WP_OPT_FUSED_RERANK: v->fused_rerank = value != 0; return WP_OK;
     case WP_OPT_COVER_ANCHORS: v->cover_anchors = value != 0; return WP_OK;
+    case WP_OPT_ARENA_GUARD: v->arena_guard = value != 0; return WP_OK;
+    case WP_OPT_DEVICES: v->n_devices = value < 0 ? -1 : static_cast<int>(std::max<int64_t>(value, 1)); return WP_OK;
   }
   g_last_error = "unknown option";
   return WP_ERR_ARG;
@@ -933,9 +1070,253 @@ int wp_linear_encode_device(wp_vocab *v, const void *d_utf8, size_t nbytes, cons
   return guarded([&] {
     if ((reinterpret_cast<uintptr_t>(d_utf8) & 3u) != 0) throw std::invalid_argument("device text must be 4-byte aligned");
     size_t n = 0;
-    encode_on_device(v, static_cast<const uint8_t *>(d_utf8), nbytes, &n);
-    *d_ids = n ? v->ctx->d_ids : nullptr;
+    Context *c = get_context(v);
+    encode_on_device(v, c, static_cast<const uint8_t *>(d_utf8), nbytes, &n, v->stats);
+    v->stats.n_devices = 1;
+    *d_ids = n ? c->d_ids : nullptr;
     *n_ids = n;
+  });
+}
+
+}  // extern "C"
+
+// ---- host buffers for the ids ------------------------------------------------------------------------
+// The ids leave the device into page-locked host memory (a download into freshly malloc'd pages runs
+// at 13-26 GB/s, into pinned memory at the link rate) and that very block is handed to the caller;
+// wp_free() recognises it and puts it back into a small pool instead of unpinning it.
+namespace {
+struct PinnedPool {
+  std::mutex mu;
+  std::unordered_map<void *, size_t> owned;       // every live pinned block (handed out or pooled) -> capacity
+  std::vector<std::pair<size_t, void *>> pooled;  // free blocks
+  static constexpr size_t kMaxPooledBlocks = 4;
+  static constexpr size_t kMaxPooledBytes = size_t(6) << 30;
+  void *take(size_t bytes) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      size_t best = pooled.size();
+      for (size_t i = 0; i < pooled.size(); i++) {
+        if (pooled[i].first >= bytes && (best == pooled.size() || pooled[i].first < pooled[best].first)) best = i;
+      }
+      if (best != pooled.size()) {
+        void *p = pooled[best].second;
+        pooled.erase(pooled.begin() + static_cast<long>(best));
+        return p;
+      }
+    }
+    void *p = nullptr;
+    const size_t want = bytes + bytes / 8 + 4096;
+    WP_HIP(hipHostMalloc(&p, want));
+    std::lock_guard<std::mutex> g(mu);
+    owned[p] = want;
+    return p;
+  }
+  // true: p was one of ours (now pooled or released)
+  bool give_back(void *p) {
+    size_t cap = 0;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto it = owned.find(p);
+      if (it == owned.end()) return false;
+      cap = it->second;
+      size_t bytes = cap;
+      for (auto &b : pooled) bytes += b.first;
+      if (pooled.size() < kMaxPooledBlocks && bytes <= kMaxPooledBytes) {
+        pooled.emplace_back(cap, p);
+        return true;
+      }
+      owned.erase(it);
+    }
+    (void)hipHostFree(p);
+    return true;
+  }
+};
+PinnedPool &id_pool() {
+  static PinnedPool *pool = new PinnedPool();  // never destroyed: blocks may outlive static destruction order
+  return *pool;
+}
+struct PinnedBlock {  // returns the block to the pool unless release()d to the caller
+  void *p = nullptr;
+  explicit PinnedBlock(size_t bytes) : p(id_pool().take(bytes)) {}
+  ~PinnedBlock() {
+    if (p) id_pool().give_back(p);
+  }
+  void *release() {
+    void *r = p;
+    p = nullptr;
+    return r;
+  }
+};
+
+using wp_clock = std::chrono::steady_clock;
+double ms_since(wp_clock::time_point t0) { return std::chrono::duration<double, std::milli>(wp_clock::now() - t0).count(); }
+
+// uploads [utf8, utf8 + nbytes) into c's text buffer (padded as the decoder expects) on c's stream
+void upload_text(Context *c, const char *utf8, size_t nbytes) {
+  c->text_buf.ensure(nbytes + 64);
+  WP_HIP(hipMemsetAsync(static_cast<char *>(c->text_buf.p) + (nbytes & ~static_cast<size_t>(15)), 0, 32, c->stream));
+  WP_HIP(hipMemcpyAsync(c->text_buf.p, utf8, nbytes, hipMemcpyHostToDevice, c->stream));
+}
+
+bool ascii_space(uint8_t b) { return (b >= 0x09 && b <= 0x0d) || b == 0x20; }
+
+// Cuts [0, nbytes) into `parts` ranges at ASCII whitespace (no word straddles two shards),
+// balanced by code points rather than bytes: the cost of a shard follows its symbol count, and a
+// mixed-script corpus has 1-3 bytes per code point depending on where one looks.  Code points are
+// estimated from every 64th 4 KB page (lead bytes = bytes that are not 10xxxxxx).
+std::vector<size_t> shard_cuts(const char *utf8, size_t nbytes, int parts) {
+  std::vector<size_t> cuts(static_cast<size_t>(parts) + 1, nbytes);
+  cuts[0] = 0;
+  if (parts <= 1) return cuts;
+  const uint8_t *b = reinterpret_cast<const uint8_t *>(utf8);
+  const size_t blocks = std::min<size_t>(static_cast<size_t>(parts) * 256, std::max<size_t>(1, nbytes / 4096));
+  const size_t blk = (nbytes + blocks - 1) / blocks;
+  std::vector<double> cum(blocks + 1, 0.0);
+  for (size_t i = 0; i < blocks; i++) {
+    const size_t lo = i * blk, hi = std::min(nbytes, lo + blk);
+    size_t leads = 0, seen = 0;
+    for (size_t page = lo; page < hi; page += 64 * 4096) {
+      const size_t e = std::min(hi, page + 4096);
+      for (size_t q = page; q < e; q++) leads += (b[q] & 0xc0u) != 0x80u;
+      seen += e - page;
+    }
+    const double density = seen ? static_cast<double>(leads) / static_cast<double>(seen) : 1.0;
+    cum[i + 1] = cum[i] + density * static_cast<double>(hi > lo ? hi - lo : 0);
+  }
+  size_t i = 0;
+  for (int r = 1; r < parts; r++) {
+    const double want = cum[blocks] * r / parts;
+    while (i + 1 < blocks && cum[i + 1] < want) i++;
+    const double span = cum[i + 1] - cum[i];
+    size_t pos = i * blk + (span > 0 ? static_cast<size_t>((want - cum[i]) / span * static_cast<double>(blk)) : 0);
+    pos = std::max(pos, cuts[static_cast<size_t>(r) - 1]);
+    while (pos < nbytes && !ascii_space(b[pos])) pos++;
+    cuts[static_cast<size_t>(r)] = std::min(pos, nbytes);
+  }
+  return cuts;
+}
+
+// One shard per entry of `devices` (ordinals may repeat: several contexts on one GPU), one host thread
+// per shard for upload + device path, then every shard's ids are downloaded straight to their place in
+// one pinned host block (exact sizes, no padded gather).
+void encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const std::vector<int> &devices, int32_t **ids,
+                  size_t *n_ids) {
+  const int G = static_cast<int>(devices.size());
+  const auto t_all = wp_clock::now();
+  if (v->multi.size() < static_cast<size_t>(G)) v->multi.resize(static_cast<size_t>(G));
+  for (int g = 0; g < G; g++) {  // (contexts are made on the calling thread: a failure here is a plain exception)
+    Context *c = v->multi[static_cast<size_t>(g)].get();
+    if (c && c->device != devices[static_cast<size_t>(g)]) v->multi[static_cast<size_t>(g)].reset();
+    if (!v->multi[static_cast<size_t>(g)]) v->multi[static_cast<size_t>(g)] = make_context(v, devices[static_cast<size_t>(g)]);
+  }
+  const std::vector<size_t> cuts = shard_cuts(utf8, nbytes, G);
+  std::vector<size_t> counts(static_cast<size_t>(G), 0);
+  std::vector<wp_stats> stats(static_cast<size_t>(G));
+  std::vector<std::string> errors(static_cast<size_t>(G));
+  std::vector<int> codes(static_cast<size_t>(G), WP_OK);
+  auto work = [&](int g) {
+    Context *c = v->multi[static_cast<size_t>(g)].get();
+    const size_t lo = cuts[static_cast<size_t>(g)], hi = cuts[static_cast<size_t>(g) + 1];
+    codes[static_cast<size_t>(g)] = guarded([&] {
+      WP_HIP(hipSetDevice(c->device));
+      std::memset(&stats[static_cast<size_t>(g)], 0, sizeof(wp_stats));
+      if (hi == lo) return;
+      upload_text(c, utf8 + lo, hi - lo);
+      encode_on_device(v, c, static_cast<const uint8_t *>(c->text_buf.p), hi - lo, &counts[static_cast<size_t>(g)],
+                       stats[static_cast<size_t>(g)]);
+    });
+    if (codes[static_cast<size_t>(g)] != WP_OK) errors[static_cast<size_t>(g)] = g_last_error;
+  };
+  {
+    std::vector<std::thread> threads;
+    for (int g = 1; g < G; g++) threads.emplace_back(work, g);
+    work(0);
+    for (auto &t : threads) t.join();
+  }
+  for (int g = 0; g < G; g++) {
+    if (codes[static_cast<size_t>(g)] == WP_OK) continue;
+    const std::string msg = "shard " + std::to_string(g) + " (device " + std::to_string(devices[static_cast<size_t>(g)]) + "): " +
+                            errors[static_cast<size_t>(g)];
+    if (codes[static_cast<size_t>(g)] == WP_ERR_TOO_LARGE) throw std::length_error(errors[static_cast<size_t>(g)]);
+    throw HipError(msg);
+  }
+  size_t total = 0;
+  std::vector<size_t> offs(static_cast<size_t>(G), 0);
+  for (int g = 0; g < G; g++) {
+    offs[static_cast<size_t>(g)] = total;
+    total += counts[static_cast<size_t>(g)];
+  }
+  const auto t_d2h = wp_clock::now();
+  if (total) {
+    PinnedBlock blk(total * sizeof(int32_t));
+    int32_t *h = static_cast<int32_t *>(blk.p);
+    for (int g = 0; g < G; g++) {  // all downloads in flight together, each on its own device's stream
+      Context *c = v->multi[static_cast<size_t>(g)].get();
+      if (!counts[static_cast<size_t>(g)]) continue;
+      WP_HIP(hipSetDevice(c->device));
+      WP_HIP(hipMemcpyAsync(h + offs[static_cast<size_t>(g)], c->d_ids, counts[static_cast<size_t>(g)] * sizeof(int32_t),
+                            hipMemcpyDeviceToHost, c->stream));
+    }
+    for (int g = 0; g < G; g++) {
+      Context *c = v->multi[static_cast<size_t>(g)].get();
+      WP_HIP(hipSetDevice(c->device));
+      WP_HIP(hipStreamSynchronize(c->stream));
+    }
+    *ids = static_cast<int32_t *>(blk.release());
+    *n_ids = total;
+  }
+  // statistics of the call: sums over the shards, the slowest shard's device times
+  wp_stats &S = v->stats;
+  S = stats[0];
+  for (int g = 1; g < G; g++) {
+    const wp_stats &T = stats[static_cast<size_t>(g)];
+    S.n_bytes += T.n_bytes;
+    S.n_text += T.n_text;
+    S.n_total += T.n_total;
+    S.n_ids += T.n_ids;
+    S.n_anchors += T.n_anchors;
+    S.alphabet = std::max(S.alphabet, T.alphabet);
+    S.rounds = std::max(S.rounds, T.rounds);
+    S.radix_passes += T.radix_passes;
+    S.radix_pass_elems += T.radix_pass_elems;
+    S.radix_digit_bytes += T.radix_digit_bytes;
+    S.ms_total = std::max(S.ms_total, T.ms_total);
+    S.ms_decode = std::max(S.ms_decode, T.ms_decode);
+    S.ms_sa = std::max(S.ms_sa, T.ms_sa);
+    S.ms_lcp = std::max(S.ms_lcp, T.ms_lcp);
+    S.ms_scan = std::max(S.ms_scan, T.ms_scan);
+    S.ms_walk = std::max(S.ms_walk, T.ms_walk);
+  }
+  S.n_devices = G;
+  S.ms_d2h = ms_since(t_d2h);
+  S.ms_host_total = ms_since(t_all);
+}
+
+std::vector<int> resolve_devices(const int *devices, int n_devices) {
+  std::vector<int> out;
+  if (devices && n_devices > 0) {
+    out.assign(devices, devices + n_devices);
+    return out;
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+    throw HipError("no HIP device available: the Linear WordPiece path has no CPU fallback");
+  }
+  const int want = n_devices <= 0 ? count : std::min(n_devices, count);
+  for (int d = 0; d < want; d++) out.push_back(d);
+  return out;
+}
+}  // namespace
+
+extern "C" {
+
+int wp_linear_encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const int *devices, int n_devices,
+                           int32_t **ids, size_t *n_ids) {
+  return guarded([&] {
+    *ids = nullptr;
+    *n_ids = 0;
+    if (nbytes == 0) return;  // linear.cpp:323-325
+    encode_multi(v, utf8, nbytes, resolve_devices(devices, n_devices), ids, n_ids);
   });
 }
 
@@ -944,28 +1325,49 @@ int wp_linear_encode(wp_vocab *v, const char *utf8, size_t nbytes, int32_t **ids
     *ids = nullptr;
     *n_ids = 0;
     if (nbytes == 0) return;  // linear.cpp:323-325: the vocab path is not touched
+    // WP_OPT_DEVICES / env WP_DEVICES: shard over several GPUs (inputs too small to be worth it stay on one)
+    if (v->n_devices != 1 && nbytes >= (size_t(1) << 22)) {
+      std::vector<int> devs = resolve_devices(nullptr, v->n_devices);
+      const size_t per = size_t(1) << 21;  // at least 2 MB per shard
+      if (devs.size() > nbytes / per) devs.resize(std::max<size_t>(1, nbytes / per));
+      if (devs.size() > 1) {
+        encode_multi(v, utf8, nbytes, devs, ids, n_ids);
+        return;
+      }
+    }
+    const auto t_all = wp_clock::now();
     Context *c = get_context(v);
-    c->text_buf.ensure(nbytes + 64);
-    WP_HIP(hipMemsetAsync(static_cast<char *>(c->text_buf.p) + (nbytes & ~static_cast<size_t>(15)), 0, 32, c->stream));
-    using clk = std::chrono::steady_clock;
-    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
-    auto t0 = clk::now();
-    WP_HIP(hipMemcpyAsync(c->text_buf.p, utf8, nbytes, hipMemcpyHostToDevice, c->stream));
+    auto t0 = wp_clock::now();
+    upload_text(c, utf8, nbytes);
     if (v->stage_timing) WP_HIP(hipStreamSynchronize(c->stream));
     const double ms_h2d = ms_since(t0);
     size_t n = 0;
-    encode_on_device(v, static_cast<const uint8_t *>(c->text_buf.p), nbytes, &n);
-    t0 = clk::now();
+    encode_on_device(v, c, static_cast<const uint8_t *>(c->text_buf.p), nbytes, &n, v->stats);
+    t0 = wp_clock::now();
     if (n) {
-      int32_t *h = static_cast<int32_t *>(std::malloc(n * sizeof(int32_t)));
-      if (!h) throw std::runtime_error("out of host memory");
-      WP_HIP(hipMemcpyAsync(h, c->d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      PinnedBlock blk(n * sizeof(int32_t));
+      WP_HIP(hipMemcpyAsync(blk.p, c->d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
       WP_HIP(hipStreamSynchronize(c->stream));
-      *ids = h;
+      *ids = static_cast<int32_t *>(blk.release());
       *n_ids = n;
     }
+    v->stats.n_devices = 1;
     v->stats.ms_h2d = v->stage_timing ? ms_h2d : 0.0;
     v->stats.ms_d2h = ms_since(t0);
+    v->stats.ms_host_total = ms_since(t_all);
+  });
+}
+
+int wp_reserve(wp_vocab *v, size_t nbytes) {
+  return guarded([&] {
+    Context *c = get_context(v);
+    // arenas as an encode of `nbytes` of text would size them (about 100 bytes per symbol, DESIGN.md section 3;
+    // an estimate: an encode that needs more grows them as before)
+    const size_t n = nbytes + 1 + v->hv.stream.size();
+    c->text_buf.ensure(nbytes + 64);
+    c->a_buf.ensure(nbytes + nbytes / 512 + (size_t(1) << 20) + (v->keep_debug ? 4 * nbytes : 0));
+    c->b_buf.ensure(108 * n + (v->keep_debug ? 4 * n : 0) + (size_t(64) << 20));
+    PinnedBlock warm(nbytes + (size_t(1) << 20));  // about a quarter of an id per byte, 4 bytes each
   });
 }
 
@@ -1081,7 +1483,7 @@ int wp_linear_encode_external(const char *text_file, const char *vocab_file, con
       WP_HIP(hipMemsetAsync(static_cast<char *>(c->text_buf.p) + (batch & ~static_cast<size_t>(15)), 0, 32, st));
       WP_HIP(hipMemcpyAsync(c->text_buf.p, begin, batch, hipMemcpyHostToDevice, st));
       size_t n = 0;
-      encode_on_device(v, static_cast<const uint8_t *>(c->text_buf.p), batch, &n);
+      encode_on_device(v, c, static_cast<const uint8_t *>(c->text_buf.p), batch, &n, v->stats);
       if (n > 0) {
         // utils.cpp:30-35 format ("<id> " per id) on the device: byte counts, 64-bit offsets, text
         const size_t tiles = cdiv(n, kFmtTile);
@@ -1179,7 +1581,10 @@ int wp_linear_debug_fetch(const wp_vocab *v, int which, int32_t *out, size_t cap
   });
 }
 
-void wp_free(void *p) { std::free(p); }
+void wp_free(void *p) {
+  if (!p) return;
+  if (!id_pool().give_back(p)) std::free(p);
+}
 const char *wp_last_error(void) { return g_last_error.c_str(); }
 int wp_device_count(void) {
   int count = 0;

@@ -128,24 +128,29 @@ __global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const uint32_t *__r
 
 // single block: in-place exclusive scan of m values; writes the grand total to *total
 // (n_dev, optional: only the tiles that hold elements below *n_dev are non-zero and visited)
+// (total64, optional: the same sum without wrapping — the code point count of inputs beyond 4 GB)
 __global__ __launch_bounds__(kBlock) void scan_spine_kernel(uint32_t *__restrict__ sums, size_t m,
                                                             uint32_t *__restrict__ total,
-                                                            const uint32_t *__restrict__ n_dev) {
+                                                            const uint32_t *__restrict__ n_dev,
+                                                            unsigned long long *__restrict__ total64) {
   __shared__ uint32_t sm[8];
   if (n_dev) m = min(m, (static_cast<size_t>(*n_dev) + kScanTile - 1) / kScanTile);
   uint32_t carry = 0;
+  unsigned long long carry64 = 0;
   for (size_t base = 0; base < m; base += kBlock) {
     size_t i = base + threadIdx.x;
     uint32_t v = i < m ? sums[i] : 0, tot;
     uint32_t ex = block_excl_sum(v, sm, tot);
     if (i < m) sums[i] = carry + ex;
     carry += tot;
+    carry64 += tot;
   }
   if (threadIdx.x == 0 && total) *total = carry;
+  if (threadIdx.x == 0 && total64) *total64 = carry64;
 }
 
-__global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t *__restrict__ in,
-                                                            uint32_t *__restrict__ out, size_t n,
+// (in == out is allowed — most callers scan in place — so the two carry no __restrict__)
+__global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t *in, uint32_t *out, size_t n,
                                                             const uint32_t *__restrict__ tile_prefix,
                                                             const uint32_t *__restrict__ n_dev) {
   __shared__ uint32_t sm[8];
@@ -173,14 +178,17 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t *__re
 
 // tmp must hold cdiv(n, kScanTile) + 1 uint32; `total` (device pointer, optional) gets the sum.
 inline void device_exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, uint32_t *tmp,
-                                  uint32_t *total, hipStream_t st, const uint32_t *n_dev = nullptr) {
+                                  uint32_t *total, hipStream_t st, const uint32_t *n_dev = nullptr,
+                                  unsigned long long *total64 = nullptr) {
   if (n == 0) {
     if (total) WP_HIP(hipMemsetAsync(total, 0, sizeof(uint32_t), st));
+    if (total64) WP_HIP(hipMemsetAsync(total64, 0, sizeof(unsigned long long), st));
     return;
   }
   unsigned tiles = cdiv(n, kScanTile);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(tiles), dim3(kBlock), 0, st, in, n, tmp, n_dev);
-  hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(kBlock), 0, st, tmp, static_cast<size_t>(tiles), total, n_dev);
+  hipLaunchKernelGGL(scan_spine_kernel, dim3(1), dim3(kBlock), 0, st, tmp, static_cast<size_t>(tiles), total, n_dev,
+                     total64);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(tiles), dim3(kBlock), 0, st, in, out, n, tmp, n_dev);
   WP_LAUNCH_CHECK();
 }

@@ -80,8 +80,13 @@ __device__ __forceinline__ uint32_t wave_rank_digit(volatile uint32_t *cnt, uint
 // prefixes in (digit, tile) order; the apply kernel rewrites every row as global offsets.
 constexpr int kColChunk = 64;
 
+// dig != nullptr: the digits of this pass were written as one byte per key by the previous pass's
+// scatter (or by the key builder): the kernel then reads 1 byte per key instead of sizeof(KeyT).
+// Counting does not care which thread sees which key of the tile, so a thread takes ITEMS consecutive
+// bytes (8-byte loads) and "round j" of a wave is byte j of every lane.
 template <typename KeyT, int ITEMS>
-__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restrict__ keys, size_t n,
+__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restrict__ keys,
+                                                            const uint8_t *__restrict__ dig, size_t n,
                                                             int begin_bit, uint32_t mask,
                                                             uint32_t *__restrict__ table,
                                                             uint32_t *__restrict__ chunk_sums, int lds_atomics) {
@@ -99,17 +104,34 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   volatile uint32_t *mycnt = sh[w];
-  const size_t base = static_cast<size_t>(blockIdx.x) * (kBlock * ITEMS) + static_cast<size_t>(w) * (kWave * ITEMS);
-  KeyT key[ITEMS];
+  const size_t tile_base = static_cast<size_t>(blockIdx.x) * (kBlock * ITEMS);
+  const size_t base = tile_base + static_cast<size_t>(w) * (kWave * ITEMS);
+  uint32_t dg[ITEMS];
+  size_t idx0, idx_step;  // element index of round j: idx0 + j * idx_step
+  if (dig) {
+    static_assert(ITEMS % 4 == 0, "digit bytes are loaded as words");
+    idx0 = tile_base + static_cast<size_t>(threadIdx.x) * ITEMS;
+    idx_step = 1;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(dig + idx0);  // tile bases and ITEMS are multiples of 4
 #pragma unroll
-  for (int j = 0; j < ITEMS; j++) {
-    const size_t i = base + static_cast<size_t>(j) * kWave + lane;
-    key[j] = i < n ? keys[i] : static_cast<KeyT>(0);
+    for (int q = 0; q < ITEMS / 4; q++) {
+      const uint32_t wv = idx0 + 4 * q < n ? src[q] : 0u;  // (the digit arrays are padded past n)
+#pragma unroll
+      for (int b = 0; b < 4; b++) dg[4 * q + b] = (wv >> (8 * b)) & 0xffu;
+    }
+  } else {
+    idx0 = base + lane;
+    idx_step = kWave;
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+      const size_t i = idx0 + static_cast<size_t>(j) * kWave;
+      dg[j] = i < n ? (static_cast<uint32_t>(keys[i] >> begin_bit) & mask) : 0u;
+    }
   }
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
-    const size_t i = base + static_cast<size_t>(j) * kWave + lane;
-    const uint32_t d = static_cast<uint32_t>(key[j] >> begin_bit) & mask;
+    const size_t i = idx0 + static_cast<size_t>(j) * idx_step;
+    const uint32_t d = dg[j];
 #if defined(WP_HIST_NOCOUNT)  // probe only (profiles/tools/hist_probe.hip): loads without counting
     if (i < n && d == 0x1ffu) sh[w][0] = 1;
 #else
@@ -223,7 +245,10 @@ template <typename KeyT, int ITEMS>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
     uint32_t *__restrict__ vout, size_t n, int begin_bit, uint32_t mask,
-    const uint32_t *__restrict__ goff) {
+    const uint32_t *__restrict__ goff, uint8_t *__restrict__ dout, int next_bit, uint32_t next_mask) {
+  // dout != nullptr: also leave the next pass's digit of every key as one byte at its new position,
+  // so that the next histogram reads 1 byte per key instead of the key (a pass is the
+  // 12-byte record read and written; this adds 1 + 1)
   constexpr int TILE = kBlock * ITEMS;
   constexpr int WAVES = kBlock / kWave;
   __shared__ uint32_t wcnt[WAVES][kRadixBins];
@@ -309,6 +334,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
       const size_t o = static_cast<size_t>(gbase[d]) + k;
       kout[o] = kk;
       vout[o] = svals[k];
+      if (dout) dout[o] = static_cast<uint8_t>(static_cast<uint32_t>(kk >> next_bit) & next_mask);
     }
   }
 }
@@ -353,6 +379,7 @@ struct EventSpans {
 struct RadixStats {
   int passes = 0;
   long long elems = 0;
+  long long digit_bytes = 0;  // digit bytes written by scatter launches (1 per element and launch)
   EventSpans spans;  // around every scatter launch
 };
 
@@ -373,70 +400,100 @@ struct BitRange {
 
 // Sorts the given bit ranges of the keys, least significant range first (stable LSD).  Data
 // ping-pongs between (k0,v0) and (k1,v1); returns 0 or 1 = which pair holds the result.
-// tmp: radix_tmp_words<KeyT>(n) uint32.
+// tmp: tmp_words uint32, at least radix_tmp_words<KeyT>(n) (checked: the table | chunk_pre |
+// chunk_sums x kMaxZeroedPasses layout below must fit).
 // identity_vals: the input values are 0..n-1 and v0 need not hold them (the first pass makes them up)
 // uniform_low_bits: digits below this bit are close to uniformly distributed (histogram by LDS atomics)
+// dg0/dg1 (optional, n + 64 bytes each, pairs with k0/k1): digit bytes — every scatter leaves the next
+// pass's digits there; dg0_ready: dg0 already holds the first pass's digits (written by the key builder)
+struct DigitBytes {
+  uint8_t *dg0 = nullptr, *dg1 = nullptr;
+  bool dg0_ready = false;
+};
+
 template <typename KeyT>
 int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, const BitRange *ranges,
-                      int nranges, uint32_t *tmp, hipStream_t st, RadixStats *stats, bool identity_vals = false,
-                      int uniform_low_bits = 0) {
+                      int nranges, uint32_t *tmp, size_t tmp_words, hipStream_t st, RadixStats *stats,
+                      bool identity_vals = false, int uniform_low_bits = 0, DigitBytes db = DigitBytes()) {
   int cur = 0;
   if (n == 0) return cur;
   const bool small = n <= kRadixSmallN;
-  if (small) stats = nullptr;  // the roofline statistics describe the full-size configuration only
+  if (small) {
+    stats = nullptr;  // the roofline statistics describe the full-size configuration only
+    db = DigitBytes();
+  }
   const unsigned ntiles = cdiv(n, small ? RadixCfg<KeyT>::kSmallTile : RadixCfg<KeyT>::kTile);
   const unsigned nchunks = cdiv(ntiles, kColChunk);
   const size_t h = static_cast<size_t>(ntiles) * kRadixBins;
   const size_t cs_words = static_cast<size_t>(nchunks + 1) * kRadixBins;
+  if (h + (kMaxZeroedPasses + 1) * cs_words > tmp_words) {
+    throw std::logic_error("radix_sort_ranges: temporary buffer too small (" + std::to_string(tmp_words) + " words for " +
+                           std::to_string(n) + " elements)");
+  }
   uint32_t *table = tmp, *chunk_pre = tmp + h, *chunk_sums0 = chunk_pre + cs_words;
   // every pass adds into its own chunk-sum table; the first kMaxZeroedPasses are cleared at once
   WP_HIP(hipMemsetAsync(chunk_sums0, 0, sizeof(uint32_t) * cs_words * kMaxZeroedPasses, st));
-  int pass = 0;
+  struct Pass {
+    int bit;
+    uint32_t mask;
+  };
+  std::vector<Pass> passes;
   for (int r = 0; r < nranges; r++) {
     for (int b = ranges[r].begin; b < ranges[r].end; b += kRadixBits) {
-      const uint32_t mask = (1u << min(kRadixBits, ranges[r].end - b)) - 1u;
-      KeyT *ki = cur ? k1 : k0, *ko = cur ? k0 : k1;
-      uint32_t *vi = cur ? v1 : v0, *vo = cur ? v0 : v1;
-      uint32_t *chunk_sums = chunk_sums0 + cs_words * static_cast<size_t>(pass % kMaxZeroedPasses);
-      if (pass >= kMaxZeroedPasses) WP_HIP(hipMemsetAsync(chunk_sums, 0, sizeof(uint32_t) * cs_words, st));
-      pass++;
-      if (small) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT, RadixCfg<KeyT>::kSmallItems>), dim3(ntiles),
-                           dim3(kBlock), 0, st, ki, n, b, mask, table, chunk_sums, 0);
-      } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT, RadixCfg<KeyT>::kItems>), dim3(ntiles),
-                           dim3(kBlock), 0, st, ki, n, b, mask, table, chunk_sums, b < uniform_low_bits ? 1 : 0);
-      }
-      hipLaunchKernelGGL(radix_spine_kernel, dim3(1), dim3(kSpineThreads), 0, st, chunk_sums, chunk_pre, nchunks);
-      hipLaunchKernelGGL(radix_apply_kernel, dim3(nchunks), dim3(kRadixBins), 0, st, table, chunk_pre, ntiles);
-      if (stats) stats->spans.begin(st);
-      const uint32_t *vsrc = identity_vals ? static_cast<const uint32_t *>(nullptr) : vi;
-      if (small) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kSmallItems>), dim3(ntiles),
-                           dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table);
-      } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems>), dim3(ntiles),
-                           dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table);
-      }
-      identity_vals = false;
-      WP_LAUNCH_CHECK();
-      if (stats) {
-        stats->spans.end(st);
-        stats->passes++;
-        stats->elems += static_cast<long long>(n);
-      }
-      cur ^= 1;
+      passes.push_back({b, (1u << std::min(kRadixBits, ranges[r].end - b)) - 1u});
     }
+  }
+  for (size_t pi = 0; pi < passes.size(); pi++) {
+    const int pass = static_cast<int>(pi), b = passes[pi].bit;
+    const uint32_t mask = passes[pi].mask;
+    KeyT *ki = cur ? k1 : k0, *ko = cur ? k0 : k1;
+    uint32_t *vi = cur ? v1 : v0, *vo = cur ? v0 : v1;
+    uint32_t *chunk_sums = chunk_sums0 + cs_words * static_cast<size_t>(pass % kMaxZeroedPasses);
+    if (pass >= kMaxZeroedPasses) WP_HIP(hipMemsetAsync(chunk_sums, 0, sizeof(uint32_t) * cs_words, st));
+    // digit bytes: read where the previous pass (or the key builder) left them, written for the next pass
+    const uint8_t *dgi = nullptr;
+    if (db.dg0 && (pi > 0 || db.dg0_ready)) dgi = cur ? db.dg1 : db.dg0;
+    uint8_t *dgo = (db.dg0 && pi + 1 < passes.size()) ? (cur ? db.dg0 : db.dg1) : nullptr;
+    const int nbit = pi + 1 < passes.size() ? passes[pi + 1].bit : 0;
+    const uint32_t nmask = pi + 1 < passes.size() ? passes[pi + 1].mask : 0u;
+    if (small) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT, RadixCfg<KeyT>::kSmallItems>), dim3(ntiles),
+                         dim3(kBlock), 0, st, ki, dgi, n, b, mask, table, chunk_sums, 0);
+    } else {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT, RadixCfg<KeyT>::kItems>), dim3(ntiles),
+                         dim3(kBlock), 0, st, ki, dgi, n, b, mask, table, chunk_sums, b < uniform_low_bits ? 1 : 0);
+    }
+    hipLaunchKernelGGL(radix_spine_kernel, dim3(1), dim3(kSpineThreads), 0, st, chunk_sums, chunk_pre, nchunks);
+    hipLaunchKernelGGL(radix_apply_kernel, dim3(nchunks), dim3(kRadixBins), 0, st, table, chunk_pre, ntiles);
+    if (stats) stats->spans.begin(st);
+    const uint32_t *vsrc = identity_vals ? static_cast<const uint32_t *>(nullptr) : vi;
+    if (small) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kSmallItems>), dim3(ntiles),
+                         dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask);
+    } else {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems>), dim3(ntiles),
+                         dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask);
+    }
+    identity_vals = false;
+    WP_LAUNCH_CHECK();
+    if (stats) {
+      stats->spans.end(st);
+      stats->passes++;
+      stats->elems += static_cast<long long>(n);
+      if (dgo) stats->digit_bytes += static_cast<long long>(n);
+    }
+    cur ^= 1;
   }
   return cur;
 }
 
 template <typename KeyT>
 int radix_sort_pairs(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, int begin_bit, int end_bit,
-                     uint32_t *tmp, hipStream_t st, RadixStats *stats, bool identity_vals = false,
-                     int uniform_low_bits = 0) {
+                     uint32_t *tmp, size_t tmp_words, hipStream_t st, RadixStats *stats, bool identity_vals = false,
+                     int uniform_low_bits = 0, DigitBytes db = DigitBytes()) {
   BitRange r{begin_bit, end_bit};
-  return radix_sort_ranges<KeyT>(k0, v0, k1, v1, n, &r, 1, tmp, st, stats, identity_vals, uniform_low_bits);
+  return radix_sort_ranges<KeyT>(k0, v0, k1, v1, n, &r, 1, tmp, tmp_words, st, stats, identity_vals, uniform_low_bits,
+                                 db);
 }
 
 }  // namespace wp

@@ -37,7 +37,18 @@ struct RerankAgg {
 struct DepthRule {
   uint32_t need;  // a tied group retires once its depth reaches this (depth-capped mode)
   int full;       // 1: only singletons retire (true suffix array)
+  // round 0, depth-capped mode (prune.h): need_map[k] != 0 iff sorted position k lies in a group that
+  // carries the key of an eligible token longer than the key; all other groups retire at once
+  const uint8_t *need_map;
 };
+
+template <bool ROUND0>
+__device__ __forceinline__ bool rr_stays_active(const DepthRule &rule, uint32_t nd, size_t k) {
+  if (rule.full) return true;
+  if (nd >= rule.need) return false;
+  if (ROUND0 && rule.need_map) return rule.need_map[k] != 0;
+  return true;
+}
 
 __device__ __forceinline__ void rr_flags(const uint64_t *__restrict__ keys, size_t m, size_t k, bool &flag,
                                          bool &single) {
@@ -86,13 +97,15 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
         if (ROUND0) {
           nd = static_cast<uint32_t>(count_key_symbols(keys[k], kKeyBits, s_fl, uniform_bits));
         } else {
+          // the second key is 1 + rank of suffix vals[k] + d (0: past the end), i.e. 1 + the first slot of
+          // that suffix's group, where its depth is kept: no need to go through rank[] again
           const uint32_t d = adep[k];
-          const size_t t = static_cast<size_t>(vals[k]) + d;
-          const uint32_t dj = t < n ? gdepth[rd[t]] : 0u;
+          const uint32_t r2 = static_cast<uint32_t>(keys[k]);
+          const uint32_t dj = r2 ? gdepth[r2 - 1u] : 0u;
           nd = min(d + dj, 0x7fffffffu);
         }
         tdep[k] = nd;
-        act = rule.full || nd < rule.need;
+        act = rr_stays_active<ROUND0>(rule, nd, k);
       }
     }
     const uint64_t bf = __ballot(f), ba = __ballot(act), bh = __ballot(f && act);
@@ -306,11 +319,11 @@ __device__ __forceinline__ void rr_first_half(RrTile &T, const uint64_t *__restr
           nd = static_cast<uint32_t>(count_key_symbols(me, kKeyBits, s_fl, uniform_bits));
         } else {
           const uint32_t d = adep[k];
-          const size_t t = static_cast<size_t>(vals[k]) + d;
-          const uint32_t dj = t < n ? gdepth_in[rd[t]] : 0u;
+          const uint32_t r2 = static_cast<uint32_t>(me);
+          const uint32_t dj = r2 ? gdepth_in[r2 - 1u] : 0u;
           nd = min(d + dj, 0x7fffffffu);
         }
-        act = rule.full || nd < rule.need;
+        act = rr_stays_active<ROUND0>(rule, nd, k);
       }
       if (ROUND0) {
         nd = min(nd, 0xffffu);
