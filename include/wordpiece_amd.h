@@ -88,6 +88,26 @@ int wp_linear_encode_file(const char *text_file, const char *vocab_file, int32_t
 int wp_linear_encode_external(const char *text_file, const char *vocab_file, const char *out_file,
                               size_t memory_limit);
 
+/* ---- the sibling algorithm: word_piece::fast (src/word_piece.hpp:23-36, src/fast.cpp) ----
+ * Per word, longest-match-first against the vocabulary (fast.cpp:19-150) — on the GPU a trie walk per
+ * word (csrc/fast.h).  Same ids as the Linear path on vocabularies whose tokens do not span spacing
+ * chars (tests/tests.cpp:80-97 asserts linear == fast); an independent on-device cross-check.
+ * replaces word_piece::fast::encode(text, vocab)              word_piece.hpp:25, fast.cpp:161-164 */
+int wp_fast_encode(wp_vocab *v, const char *utf8, size_t nbytes, int32_t **ids, size_t *n_ids);
+/* text and ids in device memory, same buffer contract as wp_linear_encode_device */
+int wp_fast_encode_device(wp_vocab *v, const void *d_utf8, size_t nbytes, const int32_t **d_ids,
+                          size_t *n_ids);
+/* replaces word_piece::fast::encode(text_file, vocab_file)   word_piece.hpp:27, fast.cpp:166-170 */
+int wp_fast_encode_file(const char *text_file, const char *vocab_file, int32_t **ids, size_t *n_ids);
+/* replaces word_piece::fast::encodeExternal(...)              word_piece.hpp:31-34, fast.cpp:189-220
+ * batches of memory_limit/2 bytes extended to the next space; same id text format. */
+int wp_fast_encode_external(const char *text_file, const char *vocab_file, const char *out_file,
+                            size_t memory_limit);
+/* UTF-8 of the stored word of vocab line i (the "##" of continuation tokens stripped, utils.cpp:83-85):
+ * what word_piece::fast::decode (fast.cpp:172-187) assembles its strings from.  Returns the length in
+ * bytes (-1: no such line) and copies at most `cap` bytes into buf. */
+int64_t wp_vocab_token_utf8(const wp_vocab *v, int64_t i, char *buf, size_t cap);
+
 /* ---- options ---- */
 #define WP_OPT_FULL_DEPTH 1   /* 1: sort suffixes to full depth (true suffix array).  0 (default):
                                  stop prefix doubling once the sorted depth exceeds the longest

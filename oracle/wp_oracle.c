@@ -650,6 +650,191 @@ int wpo_encode_mt(const wpo_vocab *v, const uint8_t *text, size_t nbytes, int th
   return encode_common(v, text, nbytes, threads <= 0 ? 0 : threads, ids, n_ids);
 }
 
+/* ------------------------------------------------------------------------ */
+/* fast.cpp:19-150 encodeFastWordPieceImpl — the sibling algorithm            */
+/* (word_piece::fast, src/word_piece.hpp:23-36): per word, longest-match-first */
+/* lookups of text segments in two maps (prefix-class / ##-class tokens).      */
+/* The reference's std::unordered_map<VectorSegment,int> is restated as an     */
+/* open-addressing table over (length, polynomial hash), verified by a symbol  */
+/* compare; operator[] assignment = the last of equal words wins (fast.cpp:34).*/
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  int32_t *slot; /* token index or -1 */
+  size_t mask;
+} fmap;
+
+static uint64_t fhash_step(uint64_t h, uint32_t c) { return (h * 1099511628211ull) ^ (uint64_t)(c + 0x9e3779b9u); }
+
+static void fmap_init(fmap *m, size_t items) {
+  size_t cap = 16;
+  while (cap < 2 * items + 2) cap *= 2;
+  m->slot = (int32_t *)malloc(cap * sizeof(int32_t));
+  for (size_t i = 0; i < cap; i++) m->slot[i] = -1;
+  m->mask = cap - 1;
+}
+
+static void fmap_put(fmap *m, const wpo_vocab *v, int32_t id) { /* fast.cpp:34: (*word_to_id)[segment] = i */
+  const wpo_token *t = &v->tok[id];
+  uint64_t h = 1469598103934665603ull;
+  for (int64_t k = 0; k < t->len; k++) h = fhash_step(h, t->word[k]);
+  size_t p = (size_t)h & m->mask;
+  for (;;) {
+    int32_t cur = m->slot[p];
+    if (cur < 0) {
+      m->slot[p] = id;
+      return;
+    }
+    const wpo_token *o = &v->tok[cur];
+    if (o->len == t->len && memcmp(o->word, t->word, sizeof(uint32_t) * (size_t)t->len) == 0) {
+      m->slot[p] = id; /* same word: the later line replaces the earlier one */
+      return;
+    }
+    p = (p + 1) & m->mask;
+  }
+}
+
+static int32_t fmap_find(const fmap *m, const wpo_vocab *v, const uint32_t *seg, int64_t len, uint64_t h) {
+  size_t p = (size_t)h & m->mask;
+  for (;;) {
+    int32_t cur = m->slot[p];
+    if (cur < 0) return -1;
+    const wpo_token *o = &v->tok[cur];
+    if (o->len == len && memcmp(o->word, seg, sizeof(uint32_t) * (size_t)len) == 0) return cur;
+    p = (p + 1) & m->mask;
+  }
+}
+
+typedef struct {
+  const wpo_vocab *v;
+  const uint32_t *text;
+  int64_t n_text;
+  fmap prefix_to_id, suffix_to_id;
+  int64_t max_len;
+  uint64_t *hbuf; /* per worker: prefix hashes of the current segment */
+} fast_ctx;
+
+static int fast_is_word_prefix(const fast_ctx *c, int64_t index) { /* fast.cpp:39-42 */
+  return index == 0 || wpo_is_spacing_char(c->text[index]) || wpo_is_spacing_char(c->text[index - 1]);
+}
+
+/* fast.cpp:44-108 worker(begin, end) */
+static void fast_worker(const fast_ctx *c, int64_t begin, int64_t end, uint64_t *hbuf, ivec *out) {
+  const uint32_t *text = c->text;
+  const int64_t max_len = c->max_len;
+  while (begin != end && wpo_is_space(text[begin])) ++begin; /* fast.cpp:48-50 */
+  size_t tokens_since_prefix = 0;
+  while (begin != end) {
+    int64_t word_len = 1; /* fast.cpp:55-61 */
+    if (!wpo_is_punctuation(text[begin])) {
+      int64_t lim = max_len < end - begin ? max_len : end - begin;
+      while (word_len < lim && !wpo_is_spacing_char(text[begin + word_len])) ++word_len;
+    }
+    const uint32_t *seg = text + begin;
+    const fmap *map = fast_is_word_prefix(c, begin) ? &c->prefix_to_id : &c->suffix_to_id; /* fast.cpp:65 */
+    uint64_t h = 1469598103934665603ull;
+    for (int64_t k = 0; k < word_len; k++) {
+      h = fhash_step(h, seg[k]);
+      hbuf[k] = h;
+    }
+    int64_t len = word_len; /* fast.cpp:67-78: find, else pop_back */
+    int32_t id = -1;
+    while (len > 0) {
+      id = fmap_find(map, c->v, seg, len, hbuf[len - 1]);
+      if (id >= 0) break;
+      --len;
+    }
+    if (len > 0) { /* found */
+      ++tokens_since_prefix;
+      ivec_push(out, id);
+      begin += len;
+      if (begin != end && fast_is_word_prefix(c, begin)) tokens_since_prefix = 0; /* fast.cpp:90-92 */
+    } else { /* fast.cpp:80-89 */
+      while (tokens_since_prefix > 0) {
+        out->n--;
+        --tokens_since_prefix;
+      }
+      ivec_push(out, c->v->unk_id);
+      begin += word_len;
+      while (begin != end && !fast_is_word_prefix(c, begin)) ++begin;
+    }
+    while (begin != end && wpo_is_space(text[begin])) ++begin; /* fast.cpp:94-96 */
+  }
+}
+
+/* fast.cpp:152-158 encodeFastWordPiece + fast.cpp:19-150.  threads > 1: the reference's own chunking
+ * (fast.cpp:113-146: chunk ends advanced to the next is_space; results concatenated in order). */
+int wpo_fast_encode_mt(const wpo_vocab *v, const uint8_t *text8, size_t nbytes, int threads, int32_t **ids,
+                       size_t *n_ids) {
+  *ids = NULL;
+  *n_ids = 0;
+  if (nbytes == 0) return WPO_OK; /* fast.cpp:154-156 */
+  uint32_t *text = (uint32_t *)malloc(sizeof(uint32_t) * (nbytes + 1));
+  if (!text) return WPO_ERR_NOMEM;
+  const int T = nthreads_eff(threads);
+  const int64_t n_text = (int64_t)decode_text(text8, nbytes, T, text);
+  fast_ctx c;
+  memset(&c, 0, sizeof(c));
+  c.v = v;
+  c.text = text;
+  c.n_text = n_text;
+  size_t np = 0, ns = 0;
+  int64_t max_len = 0;
+  for (int64_t i = 0; i < v->V; i++) { /* fast.cpp:25-35 */
+    const wpo_token *t = &v->tok[i];
+    if (t->is_special || t->is_malformed) continue;
+    if (t->len > max_len) max_len = t->len;
+    if (t->is_prefix) np++; else ns++;
+  }
+  fmap_init(&c.prefix_to_id, np);
+  fmap_init(&c.suffix_to_id, ns);
+  for (int64_t i = 0; i < v->V; i++) {
+    const wpo_token *t = &v->tok[i];
+    if (t->is_special || t->is_malformed) continue;
+    fmap_put(t->is_prefix ? &c.prefix_to_id : &c.suffix_to_id, v, (int32_t)i);
+  }
+  c.max_len = max_len < n_text ? max_len : n_text; /* fast.cpp:37 */
+  int64_t nchunks = 1;
+  if (T > 1 && n_text >= 2000000) nchunks = n_text / 1000000 < T ? n_text / 1000000 : T; /* fast.cpp:111-116 */
+  int64_t *bounds = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nchunks + 1));
+  ivec *parts = (ivec *)calloc((size_t)nchunks, sizeof(ivec));
+  const int64_t batch = n_text / nchunks + 1;
+  bounds[0] = 0;
+  for (int64_t k = 0; k < nchunks; k++) { /* fast.cpp:119-130 */
+    int64_t e = bounds[k] + batch < n_text ? bounds[k] + batch : n_text;
+    if (e < bounds[k]) e = bounds[k];
+    while (e < n_text && !wpo_is_space(text[e])) ++e;
+    if (k + 1 == nchunks) e = n_text;
+    bounds[k + 1] = e;
+  }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(T)
+  for (int64_t k = 0; k < nchunks; k++) {
+    uint64_t *hbuf = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(c.max_len + 1));
+    fast_worker(&c, bounds[k], bounds[k + 1], hbuf, &parts[k]);
+    free(hbuf);
+  }
+  size_t total = 0;
+  for (int64_t k = 0; k < nchunks; k++) total += parts[k].n;
+  int32_t *outv = (int32_t *)malloc(sizeof(int32_t) * (total ? total : 1));
+  size_t pos = 0;
+  for (int64_t k = 0; k < nchunks; k++) {
+    if (parts[k].n) memcpy(outv + pos, parts[k].d, sizeof(int32_t) * parts[k].n);
+    pos += parts[k].n;
+    free(parts[k].d);
+  }
+  free(parts);
+  free(bounds);
+  free(c.prefix_to_id.slot);
+  free(c.suffix_to_id.slot);
+  free(text);
+  *ids = outv;
+  *n_ids = total;
+  return WPO_OK;
+}
+
+int wpo_fast_encode(const wpo_vocab *v, const uint8_t *text, size_t nbytes, int32_t **ids, size_t *n_ids) {
+  return wpo_fast_encode_mt(v, text, nbytes, 1, ids, n_ids);
+}
+
 void wpo_free(void *p) { free(p); }
 
 const char *wpo_strerror(int rc) {

@@ -68,6 +68,13 @@ int wpo_encode(const wpo_vocab *v, const uint8_t *text, size_t nbytes, int32_t *
 int wpo_encode_mt(const wpo_vocab *v, const uint8_t *text, size_t nbytes, int threads,
                   int32_t **ids, size_t *n_ids);
 
+/* --- fast.cpp:19-158: the sibling algorithm word_piece::fast::encode (hash-map longest match per
+ * word).  Same ids as Linear on the reference's own test vocabularies (tests.cpp:80-97 asserts both);
+ * it differs where a token spans a spacing char or on duplicate lines (Q9). */
+int wpo_fast_encode(const wpo_vocab *v, const uint8_t *text, size_t nbytes, int32_t **ids, size_t *n_ids);
+int wpo_fast_encode_mt(const wpo_vocab *v, const uint8_t *text, size_t nbytes, int threads, int32_t **ids,
+                       size_t *n_ids);
+
 /* Intermediates for kernel-level parity tests.  All arrays malloc'd. */
 typedef struct {
   int64_t n_text;          /* code points after decode            */

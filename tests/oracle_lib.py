@@ -52,6 +52,8 @@ def lib():
                                  C.POINTER(C.c_size_t)]
         L.wpo_encode_mt.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int,
                                     C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_size_t)]
+        L.wpo_fast_encode_mt.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int,
+                                         C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_size_t)]
         L.wpo_encode_debug.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(_Debug)]
         L.wpo_debug_free.argtypes = [C.POINTER(_Debug)]
         L.wpo_free.argtypes = [C.c_void_p]
@@ -114,6 +116,18 @@ class Vocab:
             rc = lib().wpo_encode(self._h, text, len(text), C.byref(ids), C.byref(n))
         else:
             rc = lib().wpo_encode_mt(self._h, text, len(text), threads, C.byref(ids), C.byref(n))
+        if rc != 0:
+            raise OracleError(lib().wpo_strerror(rc).decode())
+        out = np.ctypeslib.as_array(ids, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int32)
+        lib().wpo_free(ids)
+        return out
+
+    def fast_encode(self, text, threads=1):
+        """word_piece::fast::encode restated (fast.cpp:19-158)."""
+        text = text if isinstance(text, (bytes, bytearray)) else text.encode("utf8")
+        ids = C.POINTER(C.c_int32)()
+        n = C.c_size_t()
+        rc = lib().wpo_fast_encode_mt(self._h, text, len(text), threads, C.byref(ids), C.byref(n))
         if rc != 0:
             raise OracleError(lib().wpo_strerror(rc).decode())
         out = np.ctypeslib.as_array(ids, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int32)

@@ -21,7 +21,7 @@ def _built():
 
 def test_header_symbols_exported():
     hdr = open(os.path.join(ROOT, "include", "wordpiece_amd.h")).read()
-    declared = set(re.findall(r"\b(wp_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(wp_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(W.ABI_SYMBOLS)
     L = W.lib()
     for s in declared:

@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "wp_vocab_unk_id", "wp_vocab_token_flags", "wp_vocab_token_len", "wp_linear_encode",
     "wp_linear_encode_device", "wp_linear_encode_file", "wp_linear_encode_external", "wp_set_option",
     "wp_get_stats", "wp_linear_debug_fetch", "wp_free", "wp_last_error", "wp_device_count",
-    "wp_linear_encode_multi", "wp_reserve",
+    "wp_linear_encode_multi", "wp_reserve", "wp_fast_encode", "wp_fast_encode_device", "wp_fast_encode_file",
+    "wp_fast_encode_external", "wp_vocab_token_utf8",
 ]
 
 
@@ -86,6 +87,12 @@ def lib():
         L.wp_linear_encode_multi.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.POINTER(i32p),
                                              C.POINTER(C.c_size_t)]
         L.wp_reserve.argtypes = [vp, C.c_size_t]
+        L.wp_fast_encode.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32p), C.POINTER(C.c_size_t)]
+        L.wp_fast_encode_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.wp_fast_encode_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(i32p), C.POINTER(C.c_size_t)]
+        L.wp_fast_encode_external.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.wp_vocab_token_utf8.argtypes = [vp, C.c_int64, C.c_char_p, C.c_size_t]
+        L.wp_vocab_token_utf8.restype = C.c_int64
         L.wp_linear_encode_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(i32p), C.POINTER(C.c_size_t)]
         L.wp_linear_encode_external.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
         L.wp_set_option.argtypes = [vp, C.c_int, C.c_int64]
@@ -158,6 +165,29 @@ class Vocab:
         n = C.c_size_t()
         _check(lib().wp_linear_encode(self._h, b, len(b), C.byref(ids), C.byref(n)))
         return _adopt_ids(ids, n.value)
+
+    def fast_encode(self, text):
+        """word_piece::fast::encode on the GPU (wp_fast_encode): host bytes/str -> numpy int32 ids."""
+        b = _bytes(text)
+        ids = C.POINTER(C.c_int32)()
+        n = C.c_size_t()
+        _check(lib().wp_fast_encode(self._h, b, len(b), C.byref(ids), C.byref(n)))
+        return _adopt_ids(ids, n.value)
+
+    def fast_encode_device(self, d_ptr, nbytes):
+        d_ids = C.c_void_p()
+        n = C.c_size_t()
+        _check(lib().wp_fast_encode_device(self._h, C.c_void_p(d_ptr), nbytes, C.byref(d_ids), C.byref(n)))
+        return d_ids.value, n.value
+
+    def token_utf8(self, i):
+        """Stored word of vocab line i as UTF-8 bytes (without "##"), or None."""
+        n = lib().wp_vocab_token_utf8(self._h, i, None, 0)
+        if n < 0:
+            return None
+        buf = C.create_string_buffer(max(n, 1))
+        lib().wp_vocab_token_utf8(self._h, i, buf, n)
+        return buf.raw[:n]
 
     def encode_multi(self, text, devices=None):
         """Host bytes -> numpy int32 ids, sharded over several GPUs behind the C ABI
@@ -253,6 +283,44 @@ class _Linear:
 
 
 linear = _Linear()
+
+
+class _Fast:
+    """word_piece::fast of the reference (src/word_piece.hpp:23-36, src/fast.cpp:159-220)."""
+
+    @staticmethod
+    def encode(text, vocab):
+        if isinstance(vocab, (str, bytes)):  # (text_file, vocab_file) overload, fast.cpp:166-170
+            ids = C.POINTER(C.c_int32)()
+            n = C.c_size_t()
+            _check(lib().wp_fast_encode_file(_bytes(text), _bytes(vocab), C.byref(ids), C.byref(n)))
+            return _adopt_ids(ids, n.value).tolist()
+        return Vocab(vocab).fast_encode(text).tolist()  # fast.cpp:161-164
+
+    @staticmethod
+    def decode(vocab_file, ids):  # fast.cpp:172-187
+        import sys
+        v = Vocab(file=vocab_file)
+        out = []
+        for i in ids:
+            if i < 0 or i >= len(v):
+                print("no token %d" % i, file=sys.stderr)
+                continue
+            flags = v.token_flags(i)
+            if flags & 4:
+                print("trying to access malformed token", file=sys.stderr)
+                continue
+            w = v.token_utf8(i)
+            out.append(w if flags & 1 else b"##" + w)
+        return out
+
+    @staticmethod
+    def encodeExternal(text_file, vocab_file, out_file, memory_limit):  # fast.cpp:189-220
+        _check(lib().wp_fast_encode_external(_bytes(text_file), _bytes(vocab_file), _bytes(out_file),
+                                             int(memory_limit)))
+
+
+fast = _Fast()
 
 
 def shard_bounds(data, world_size):

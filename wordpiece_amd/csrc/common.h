@@ -59,6 +59,7 @@ __host__ __device__ inline bool is_spacing_char(uint32_t c) {
 constexpr uint8_t kClsSpace = 1;    // is_space
 constexpr uint8_t kClsSpacing = 2;  // is_spacing_char
 constexpr uint8_t kClsSoft = 4;     // spacing char that occurs inside an eligible multi-char token
+constexpr uint8_t kClsPunct = 8;    // is_punctuation (the fast path's word rule, fast.cpp:56)
 
 // ---- UTF-8: utf8.cpp:31-90 ----------------------------------------------------------------
 // Decodes the sequence starting at p[0] with `size` bytes available.  Returns the code point or

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(kBlock) void decode_write_kernel(
   auto class_of = [&](uint32_t c) {
     uint8_t f = 0;
     if (is_space(c)) f |= kClsSpace;
+    if (is_punctuation(c)) f |= kClsPunct;
     if (is_spacing_char(c)) {
       f |= kClsSpacing;
       int lo = 0, hi = nsoft;  // sorted list of "soft" spacing chars (usually empty)
@@ -135,9 +136,10 @@ __global__ __launch_bounds__(kBlock) void decode_write_kernel(
     }
     return f;
   };
+  // (lut_excl == nullptr / sym == nullptr: no dense symbols — the fast path works on the raw code points in cps_dbg)
   if (threadIdx.x < 128) {
     const uint32_t c = threadIdx.x;
-    s_ascii[c] = static_cast<uint16_t>((static_cast<uint32_t>(class_of(c)) << 8) | ((lut_excl[c] + 1u) & 0xffu));
+    s_ascii[c] = static_cast<uint16_t>((static_cast<uint32_t>(class_of(c)) << 8) | (lut_excl ? ((lut_excl[c] + 1u) & 0xffu) : 0u));
   }
   const size_t off = static_cast<size_t>(blockIdx.x) * kDecTile + static_cast<size_t>(threadIdx.x) * kDecBytes;
   uint32_t cp[kDecBytes];
@@ -183,10 +185,10 @@ __global__ __launch_bounds__(kBlock) void decode_write_kernel(
       sv = e & 0xffu;
       f = static_cast<uint8_t>(e >> 8);
     } else {
-      sv = lut_excl[c] + 1u;
+      sv = lut_excl ? lut_excl[c] + 1u : 0u;
       f = class_of(c);
     }
-    sym[out_base + k] = static_cast<SymT>(sv);
+    if (sym) sym[out_base + k] = static_cast<SymT>(sv);
     if (sampled) atomicAdd(&shist[(sv >> hist_shift) & 255u], 1u);
     if (cps_dbg) cps_dbg[out_base + k] = c;
     cls[out_base + k] = f;

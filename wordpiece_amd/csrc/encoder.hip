@@ -23,6 +23,7 @@
 #include "../../include/wordpiece_amd.h"
 #include "code.h"
 #include "decode.h"
+#include "fast.h"
 #include "format.h"
 #include "local_sort.h"
 #include "prune.h"
@@ -143,6 +144,9 @@ struct Context {
   // vocab tables on the device
   uint32_t *d_stream = nullptr, *d_elig_start = nullptr, *d_elig_info = nullptr, *d_soft = nullptr;
   int32_t *d_elig_id = nullptr, *d_tok_len = nullptr;
+  unsigned long long *d_trie_key = nullptr;  // the fast path's token trie (vocab.h)
+  uint32_t *d_trie_child = nullptr;
+  int32_t *d_trie_id = nullptr;
   DeviceBuffer text_buf, a_buf, b_buf, fmt_buf;  // fmt_buf: id text of encodeExternal
   uint32_t *d_used = nullptr, *d_lut = nullptr, *d_scan_tmp = nullptr;  // code point tables
   uint32_t *d_scalars = nullptr;                                         // kScalars words of device scalars
@@ -191,7 +195,8 @@ static void destroy_context(Context *c) {
                   static_cast<void *>(c->d_elig_id), static_cast<void *>(c->d_tok_len),
                   static_cast<void *>(c->d_used), static_cast<void *>(c->d_lut), static_cast<void *>(c->d_scan_tmp),
                   static_cast<void *>(c->d_scalars), static_cast<void *>(c->d_code),
-                  static_cast<void *>(c->d_symhist)}) {
+                  static_cast<void *>(c->d_symhist), static_cast<void *>(c->d_trie_key),
+                  static_cast<void *>(c->d_trie_child), static_cast<void *>(c->d_trie_id)}) {
     if (p) (void)hipFree(p);
   }
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
@@ -241,6 +246,13 @@ static std::unique_ptr<Context> make_context(const wp_vocab *v, int device) {
   c->d_elig_id = upload(hv.elig_id, c->stream);
   c->d_tok_len = upload(hv.tok_len, c->stream);
   c->d_soft = upload(hv.soft, c->stream);
+  {
+    std::vector<unsigned long long> tk(hv.trie_key.begin(), hv.trie_key.end());
+    c->d_trie_key = upload(tk, c->stream);
+    WP_HIP(hipStreamSynchronize(c->stream));  // tk is a local
+  }
+  c->d_trie_child = upload(hv.trie_child, c->stream);
+  c->d_trie_id = upload(hv.trie_id, c->stream);
   WP_HIP(hipMalloc(&c->d_used, sizeof(uint32_t) * kCpTableSize));
   WP_HIP(hipMalloc(&c->d_lut, sizeof(uint32_t) * kCpTableSize));
   WP_HIP(hipMalloc(&c->d_scan_tmp, sizeof(uint32_t) * (cdiv(kCpTableSize, kScanTile) + 8)));
@@ -950,6 +962,171 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   *n_ids_out = n_ids;
 }
 
+// ---------------- word_piece::fast on the device (fast.h) ----------------
+// decode -> code points + class bytes -> anchors -> trie walk per word -> id stream.
+static void encode_fast_on_device(const wp_vocab *v, Context *c, const uint8_t *d_text, size_t nbytes, size_t *n_ids_out,
+                                  wp_stats &S) {
+  hipStream_t st = c->stream;
+  const HostVocab &hv = v->hv;
+  std::memset(&S, 0, sizeof(S));
+  S.n_bytes = static_cast<int64_t>(nbytes);
+  S.longest_token = hv.fast_max_len;
+  S.n_devices = 1;
+  c->d_ids = nullptr;
+  c->dbg = {};
+  *n_ids_out = 0;
+  if (nbytes == 0) return;  // fast.cpp:154-156
+  static const bool env_guard = env_flag("WP_ARENA_GUARD");
+  Arena aa(&c->a_buf, v->arena_guard || env_guard);
+  if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[0], st));
+  const unsigned dec_tiles = cdiv(nbytes, kDecTile);
+  uint32_t *d_tile_cnt = nullptr, *d_cnt_tmp = nullptr, *d_cps = nullptr;
+  uint8_t *d_cls = nullptr;
+  for (int pass = 0; pass < 2; pass++) {
+    d_tile_cnt = aa.take<uint32_t>(dec_tiles + 1);
+    d_cnt_tmp = aa.take<uint32_t>(cdiv(dec_tiles, kScanTile) + 8);
+    d_cps = aa.take<uint32_t>(nbytes + 1);
+    d_cls = aa.take<uint8_t>(nbytes + 16);
+    if (pass == 0) aa.commit();
+  }
+  aa.arm(st);
+  WP_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(uint32_t) * kScalars, st));
+  // (decode_count also marks used code points: not needed here, but the table is the handle's anyway)
+  hipLaunchKernelGGL(decode_count_kernel, dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes, d_tile_cnt,
+                     reinterpret_cast<unsigned long long *>(c->d_scalars + 2), c->d_used);
+  device_exclusive_scan(d_tile_cnt, d_tile_cnt, dec_tiles, d_cnt_tmp, c->d_scalars + 0, st, nullptr,
+                        reinterpret_cast<unsigned long long *>(c->d_scalars + 14));
+  WP_LAUNCH_CHECK();
+  fetch_scalars(c, 16);
+  unsigned long long n_text64;
+  std::memcpy(&n_text64, c->h_scalars + 14, sizeof(n_text64));
+  if (n_text64 > 4000000000ull) throw std::length_error("text of more than 4e9 code points");  // 32-bit positions
+  const size_t n_text = c->h_scalars[0];
+  unsigned long long dropped;
+  std::memcpy(&dropped, c->h_scalars + 2, sizeof(dropped));
+  if (dropped != 0) std::cerr << "WARNING Input contains invalid unicode characters." << std::endl;
+  S.n_text = static_cast<int64_t>(n_text);
+  S.n_total = static_cast<int64_t>(n_text);
+  if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[1], st));
+  if (n_text == 0) return;
+
+  Arena ar(&c->b_buf, aa.guard);
+  const size_t tiles = cdiv(n_text, kScanTile), atiles = cdiv(n_text, kAnchorTile);
+  const uint32_t lw_cap = static_cast<uint32_t>(n_text / kMaxAnchorGap + 2);
+  int32_t *d_emit = nullptr, *d_ids = nullptr, *d_lid = nullptr;
+  uint32_t *d_anchors = nullptr, *d_anchor_cnt = nullptr, *d_anchor_tmp = nullptr, *d_emit_cnt = nullptr, *d_emit_tmp = nullptr,
+           *jump_a = nullptr, *jump_b = nullptr, *d_lw_off = nullptr, *d_lw_fail = nullptr;
+  uint8_t *d_mark = nullptr;
+  LongWord *d_lw = nullptr;
+  for (int pass = 0; pass < 2; pass++) {
+    d_emit = ar.take<int32_t>(n_text + 1);
+    d_ids = ar.take<int32_t>(n_text + 1);
+    d_anchors = ar.take<uint32_t>(n_text + 1);
+    d_anchor_cnt = ar.take<uint32_t>(atiles + 1);
+    d_anchor_tmp = ar.take<uint32_t>(cdiv(atiles, kScanTile) + 8);
+    d_emit_cnt = ar.take<uint32_t>(tiles + 1);
+    d_emit_tmp = ar.take<uint32_t>(cdiv(tiles, kScanTile) + 8);
+    d_lid = ar.take<int32_t>(n_text + 1);
+    jump_a = ar.take<uint32_t>(n_text + 1);
+    jump_b = ar.take<uint32_t>(n_text + 1);
+    d_mark = ar.take<uint8_t>(n_text + 1);
+    d_lw = ar.take<LongWord>(lw_cap);
+    d_lw_off = ar.take<uint32_t>(lw_cap + 1);
+    d_lw_fail = ar.take<uint32_t>(lw_cap + 1);
+    if (pass == 0) ar.commit();
+  }
+  ar.arm(st);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(decode_write_kernel<uint32_t>), dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes,
+                     d_tile_cnt, static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), d_cls, d_cps,
+                     static_cast<const uint32_t *>(nullptr), 0, static_cast<uint32_t *>(nullptr), 0);
+  WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st));
+  hipLaunchKernelGGL(fast_anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, n_text, d_anchor_cnt);
+  device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st);
+  hipLaunchKernelGGL(fast_anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, n_text, d_anchor_cnt, d_anchors);
+  hipLaunchKernelGGL(fast_anchor_gap_kernel, dim3(std::min<size_t>(atiles, 1024)), dim3(kBlock), 0, st, d_anchors,
+                     c->d_scalars + 10, n_text, d_cls, c->d_scalars + 11);
+  WP_LAUNCH_CHECK();
+  fetch_scalars(c, 12);
+  const size_t n_anchors = c->h_scalars[10], max_gap = c->h_scalars[11];
+  S.n_anchors = static_cast<int64_t>(n_anchors);
+  if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[2], st));
+  FastArgs fa{d_cps, d_cls, n_text,
+              TrieView{c->d_trie_key, c->d_trie_child, c->d_trie_id, static_cast<uint32_t>(hv.trie_key.size() - 1)},
+              c->d_tok_len, hv.unk_id, static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(hv.fast_max_len), n_text)),
+              d_emit};
+  if (max_gap > kMaxAnchorGap) {  // long words: pointer doubling instead of one lane per word (walk.h)
+    hipLaunchKernelGGL(fast_long_word_collect_kernel, dim3(std::min<size_t>(cdiv(std::max<size_t>(n_anchors, 1), kBlock), 2048)),
+                       dim3(kBlock), 0, st, d_anchors, c->d_scalars + 10, n_text, d_cls, d_lw, lw_cap, c->d_scalars + 12);
+    WP_LAUNCH_CHECK();
+    fetch_scalars(c, 13);
+    const uint32_t nw = std::min(c->h_scalars[12], lw_cap);
+    if (nw > 0) {
+      std::vector<LongWord> h_lw(nw);
+      WP_HIP(hipMemcpyAsync(h_lw.data(), d_lw, sizeof(LongWord) * nw, hipMemcpyDeviceToHost, st));
+      WP_HIP(hipStreamSynchronize(st));
+      std::vector<uint32_t> h_off(nw + 1);
+      uint64_t total64 = 0;
+      uint32_t longest = 0;
+      for (uint32_t i = 0; i < nw; i++) {
+        h_off[i] = static_cast<uint32_t>(total64);
+        total64 += h_lw[i].end - h_lw[i].begin;
+        longest = std::max(longest, h_lw[i].end - h_lw[i].begin);
+      }
+      h_off[nw] = static_cast<uint32_t>(total64);
+      const uint32_t total = static_cast<uint32_t>(total64);  // <= n_text
+      WP_HIP(hipMemcpyAsync(d_lw_off, h_off.data(), sizeof(uint32_t) * (nw + 1), hipMemcpyHostToDevice, st));
+      WP_HIP(hipMemsetAsync(d_lw_fail, 0, sizeof(uint32_t) * nw, st));
+      const dim3 grid(cdiv(total, kBlock));
+      hipLaunchKernelGGL(fast_long_word_next_kernel, grid, dim3(kBlock), 0, st, fa, d_lw, d_lw_off, nw, total, d_lid, jump_a,
+                         d_mark);
+      WP_HIP(hipStreamSynchronize(st));  // h_off is a stack-owned upload source
+      uint32_t *ja = jump_a, *jb = jump_b;
+      for (uint32_t reach = 1; reach < longest; reach *= 2) {
+        hipLaunchKernelGGL(long_word_mark_kernel, grid, dim3(kBlock), 0, st, ja, total, d_mark);
+        hipLaunchKernelGGL(long_word_double_kernel, grid, dim3(kBlock), 0, st, ja, total, jb);
+        std::swap(ja, jb);
+      }
+      hipLaunchKernelGGL(long_word_mark_kernel, grid, dim3(kBlock), 0, st, ja, total, d_mark);
+      hipLaunchKernelGGL(long_word_fail_kernel, grid, dim3(kBlock), 0, st, d_lid, d_mark, d_lw_off, nw, total, d_lw_fail);
+      hipLaunchKernelGGL(fast_long_word_emit_kernel, grid, dim3(kBlock), 0, st, fa, d_lw, d_lw_off, nw, total, d_lid, d_mark,
+                         d_lw_fail);
+      WP_LAUNCH_CHECK();
+      S.anchor_mode = 2;
+    }
+  }
+  hipLaunchKernelGGL(fast_walk_kernel, dim3(cdiv(std::max<size_t>(n_anchors, 1), kBlock)), dim3(kBlock), 0, st, fa, d_anchors,
+                     c->d_scalars + 10, std::max<size_t>(n_anchors, 1));
+  hipLaunchKernelGGL(emit_count_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt);
+  device_exclusive_scan(d_emit_cnt, d_emit_cnt, tiles, d_emit_tmp, c->d_scalars + 9, st);
+  hipLaunchKernelGGL(emit_write_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt, d_ids);
+  WP_LAUNCH_CHECK();
+  if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[3], st));
+  if (ar.guard) {
+    static const uint32_t init[2] = {0u, 0xffffffffu};
+    WP_HIP(hipMemcpyAsync(c->d_scalars + 16, init, sizeof(init), hipMemcpyHostToDevice, st));
+    ar.check(st, c->d_scalars + 16);
+    aa.check(st, c->d_scalars + 16);
+    fetch_scalars(c, 18);
+    if (c->h_scalars[16] != 0) throw HipError("arena guard: guard zone overwritten in the fast path");
+    S.guard_zones = static_cast<int32_t>(ar.zones.size() + aa.zones.size());
+  }
+  fetch_scalars(c, 10);
+  const size_t n_ids = c->h_scalars[9];
+  S.n_ids = static_cast<int64_t>(n_ids);
+  if (v->stage_timing) {
+    auto span = [&](int a, int b) {
+      float ms = 0;
+      WP_HIP(hipEventElapsedTime(&ms, c->ev[a], c->ev[b]));
+      return static_cast<double>(ms);
+    };
+    S.ms_decode = span(0, 2);
+    S.ms_walk = span(2, 3);
+    S.ms_total = span(0, 3);
+  }
+  c->d_ids = d_ids;
+  *n_ids_out = n_ids;
+}
+
 }  // namespace wp
 
 wp_vocab::~wp_vocab() {
@@ -1435,14 +1612,13 @@ struct PinnedText {
 };
 }  // namespace
 
-int wp_linear_encode_external(const char *text_file, const char *vocab_file, const char *out_file,
-                              size_t memory_limit) {
+static int encode_external_impl(const char *text_file, const char *vocab_file, const char *out_file,
+                                size_t max_batch, bool fast) {
   wp_vocab *v = nullptr;
   int rc = wp_vocab_from_file(vocab_file, &v);
   if (rc != WP_OK) return rc;
   std::unique_ptr<wp_vocab> guard(v);
   return guarded([&] {
-    const size_t max_batch = memory_limit / 20;  // linear.cpp:349
     if (max_batch == 0) throw std::invalid_argument("memory_limit too small");
     MappedFile mm(text_file);
     const char *begin = mm.data;
@@ -1483,7 +1659,11 @@ int wp_linear_encode_external(const char *text_file, const char *vocab_file, con
       WP_HIP(hipMemsetAsync(static_cast<char *>(c->text_buf.p) + (batch & ~static_cast<size_t>(15)), 0, 32, st));
       WP_HIP(hipMemcpyAsync(c->text_buf.p, begin, batch, hipMemcpyHostToDevice, st));
       size_t n = 0;
-      encode_on_device(v, c, static_cast<const uint8_t *>(c->text_buf.p), batch, &n, v->stats);
+      if (fast) {
+        encode_fast_on_device(v, c, static_cast<const uint8_t *>(c->text_buf.p), batch, &n, v->stats);
+      } else {
+        encode_on_device(v, c, static_cast<const uint8_t *>(c->text_buf.p), batch, &n, v->stats);
+      }
       if (n > 0) {
         // utils.cpp:30-35 format ("<id> " per id) on the device: byte counts, 64-bit offsets, text
         const size_t tiles = cdiv(n, kFmtTile);
@@ -1534,6 +1714,85 @@ int wp_linear_encode_external(const char *text_file, const char *vocab_file, con
       if (pending[i].valid()) pending[i].get();
     }
   });
+}
+
+int wp_linear_encode_external(const char *text_file, const char *vocab_file, const char *out_file,
+                              size_t memory_limit) {
+  return encode_external_impl(text_file, vocab_file, out_file, memory_limit / 20, false);  // linear.cpp:349
+}
+
+// ---- word_piece::fast (fast.cpp:152-220) ----------------------------------------------------------------
+int wp_fast_encode_device(wp_vocab *v, const void *d_utf8, size_t nbytes, const int32_t **d_ids, size_t *n_ids) {
+  return guarded([&] {
+    if ((reinterpret_cast<uintptr_t>(d_utf8) & 3u) != 0) throw std::invalid_argument("device text must be 4-byte aligned");
+    size_t n = 0;
+    Context *c = get_context(v);
+    encode_fast_on_device(v, c, static_cast<const uint8_t *>(d_utf8), nbytes, &n, v->stats);
+    *d_ids = n ? c->d_ids : nullptr;
+    *n_ids = n;
+  });
+}
+
+int wp_fast_encode(wp_vocab *v, const char *utf8, size_t nbytes, int32_t **ids, size_t *n_ids) {
+  return guarded([&] {
+    *ids = nullptr;
+    *n_ids = 0;
+    if (nbytes == 0) return;  // fast.cpp:154-156
+    const auto t_all = wp_clock::now();
+    Context *c = get_context(v);
+    upload_text(c, utf8, nbytes);
+    size_t n = 0;
+    encode_fast_on_device(v, c, static_cast<const uint8_t *>(c->text_buf.p), nbytes, &n, v->stats);
+    if (n) {
+      PinnedBlock blk(n * sizeof(int32_t));
+      WP_HIP(hipMemcpyAsync(blk.p, c->d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      WP_HIP(hipStreamSynchronize(c->stream));
+      *ids = static_cast<int32_t *>(blk.release());
+      *n_ids = n;
+    }
+    v->stats.ms_host_total = ms_since(t_all);
+  });
+}
+
+int wp_fast_encode_file(const char *text_file, const char *vocab_file, int32_t **ids, size_t *n_ids) {
+  wp_vocab *v = nullptr;
+  int rc = wp_vocab_from_file(vocab_file, &v);
+  if (rc != WP_OK) return rc;
+  std::unique_ptr<wp_vocab> guard(v);
+  return guarded([&] {
+    MappedFile mm(text_file);
+    if (wp_fast_encode(v, mm.data, mm.size, ids, n_ids) != WP_OK) throw std::runtime_error(g_last_error);
+  });
+}
+
+int wp_fast_encode_external(const char *text_file, const char *vocab_file, const char *out_file, size_t memory_limit) {
+  return encode_external_impl(text_file, vocab_file, out_file, memory_limit / 2, true);  // fast.cpp:195
+}
+
+// UTF-8 of the stored word of line i (without the "##" of continuation tokens: utils.cpp:83-85), for
+// word_piece::fast::decode (fast.cpp:163-187).  Returns the byte length; copies at most `cap` bytes.
+int64_t wp_vocab_token_utf8(const wp_vocab *v, int64_t i, char *buf, size_t cap) {
+  if (i < 0 || static_cast<size_t>(i) >= v->hv.tokens.size()) return -1;
+  std::string out;
+  for (uint32_t cp : v->hv.tokens[static_cast<size_t>(i)].word) {  // utf8.cpp:98-121 utf8_to_chars
+    if (cp < 0x80) {
+      out.push_back(static_cast<char>(cp));
+    } else if (cp < 0x800) {
+      out.push_back(static_cast<char>(0xc0 | (cp >> 6)));
+      out.push_back(static_cast<char>(0x80 | (cp & 0x3f)));
+    } else if (cp < 0x10000) {
+      out.push_back(static_cast<char>(0xe0 | (cp >> 12)));
+      out.push_back(static_cast<char>(0x80 | ((cp >> 6) & 0x3f)));
+      out.push_back(static_cast<char>(0x80 | (cp & 0x3f)));
+    } else {
+      out.push_back(static_cast<char>(0xf0 | (cp >> 18)));
+      out.push_back(static_cast<char>(0x80 | ((cp >> 12) & 0x3f)));
+      out.push_back(static_cast<char>(0x80 | ((cp >> 6) & 0x3f)));
+      out.push_back(static_cast<char>(0x80 | (cp & 0x3f)));
+    }
+  }
+  if (buf && cap) std::memcpy(buf, out.data(), std::min(cap, out.size()));
+  return static_cast<int64_t>(out.size());
 }
 
 int wp_linear_debug_fetch(const wp_vocab *v, int which, int32_t *out, size_t capacity, size_t *n_out) {

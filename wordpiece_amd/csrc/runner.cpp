@@ -1,6 +1,6 @@
 // runner.cpp — CLI with the reference runner's positional arguments (tests/runner.cpp:13-65):
 //   runner <mode> <text_file> <vocab_file> [n_threads] [out_file] [memory_limit_mb]
-// modes: linear, linear-external.  n_threads is accepted and ignored (the work runs on the GPU).
+// modes: fast, linear, fast-external, linear-external.  n_threads is accepted and ignored (the work runs on the GPU).
 #include <fstream>
 #include <iostream>
 #include <optional>
@@ -13,7 +13,7 @@
 int main(int argc, char *argv[]) {
   if (argc < 4 || argc > 7) {
     throw std::runtime_error("Usage: ./runner <mode> <text_file> <vocab_file> [n_threads] "
-                             "[out_file] [memory_limit_mb]. Modes: linear, linear-external.");
+                             "[out_file] [memory_limit_mb]. Modes: fast, linear, fast-external, linear-external.");
   }
   const std::string mode = argv[1], text_file = argv[2], vocab_file = argv[3];
   const std::optional<std::string> out_file = argc >= 6 ? std::optional<std::string>(argv[5]) : std::nullopt;
@@ -22,16 +22,21 @@ int main(int argc, char *argv[]) {
     if (*memory_limit < 50) throw std::runtime_error("memory_limit cannot be less than 50Mb");
     *memory_limit *= 1'000'000;
   }
-  if (mode == "linear") {
-    std::vector<int> ids = word_piece::linear::encode(text_file, vocab_file);
+  if (mode == "linear" || mode == "fast") {
+    std::vector<int> ids = mode == "linear" ? word_piece::linear::encode(text_file, vocab_file)
+                                            : word_piece::fast::encode(text_file, vocab_file);
     std::cout << "Total ids " << ids.size() << std::endl;
     if (out_file) {  // utils.cpp:30-35 writeToFile
       std::ofstream fout(*out_file);
       for (int id : ids) fout << id << ' ';
     }
-  } else if (mode == "linear-external") {
+  } else if (mode == "linear-external" || mode == "fast-external") {
     if (!memory_limit.has_value()) throw std::runtime_error("For external mode provide out_file and memory_limit");
-    word_piece::linear::encodeExternal(text_file, vocab_file, out_file.value(), memory_limit.value());
+    if (mode == "linear-external") {
+      word_piece::linear::encodeExternal(text_file, vocab_file, out_file.value(), memory_limit.value());
+    } else {
+      word_piece::fast::encodeExternal(text_file, vocab_file, out_file.value(), memory_limit.value());
+    }
   } else {
     throw std::runtime_error("Unknown mode");
   }

@@ -58,6 +58,56 @@ struct HostVocab {
   std::vector<uint32_t> soft;        // sorted spacing chars occurring inside eligible multi-char tokens
   int64_t n_dup_eligible = 0;        // eligible tokens that repeat an earlier (class, word)
 
+  // word_piece::fast (fast.cpp:22-36): the two word -> id maps as one trie stored in a hash table.
+  // Node 0 / 1 = root of the prefix-class / ##-class tokens; every distinct prefix of an eligible
+  // token is a node; trie_key[h] = parent << 32 | code point, trie_child[h] = node (open addressing,
+  // kTrieEmpty = free); trie_id[node] = vocab line ending there (the last of equal words, as
+  // operator[] assignment gives in fast.cpp:34) or -1.
+  static constexpr uint64_t kTrieEmpty = ~0ull;
+  std::vector<uint64_t> trie_key;
+  std::vector<uint32_t> trie_child;
+  std::vector<int32_t> trie_id;
+  int64_t fast_max_len = 0;  // longest eligible token (fast.cpp:30)
+
+  static uint32_t trie_hash(uint64_t key) {
+    key ^= key >> 33;
+    key *= 0xff51afd7ed558ccdull;
+    key ^= key >> 29;
+    return static_cast<uint32_t>(key);
+  }
+
+  void build_trie() {
+    size_t total = 2;
+    for (const HostToken &t : tokens) {
+      if (!t.is_special && !t.is_malformed) total += t.word.size();
+    }
+    size_t cap = 64;
+    while (cap < 2 * total) cap *= 2;
+    trie_key.assign(cap, kTrieEmpty);
+    trie_child.assign(cap, 0);
+    trie_id.assign(2, -1);
+    fast_max_len = 0;
+    const uint32_t mask = static_cast<uint32_t>(cap - 1);
+    for (size_t i = 0; i < tokens.size(); i++) {
+      const HostToken &t = tokens[i];
+      if (t.is_special || t.is_malformed) continue;  // fast.cpp:27-29
+      fast_max_len = std::max<int64_t>(fast_max_len, static_cast<int64_t>(t.word.size()));
+      uint32_t node = t.is_prefix ? 0u : 1u;
+      for (uint32_t c : t.word) {
+        const uint64_t key = (static_cast<uint64_t>(node) << 32) | c;
+        uint32_t h = trie_hash(key) & mask;
+        while (trie_key[h] != kTrieEmpty && trie_key[h] != key) h = (h + 1) & mask;
+        if (trie_key[h] == kTrieEmpty) {
+          trie_key[h] = key;
+          trie_child[h] = static_cast<uint32_t>(trie_id.size());
+          trie_id.push_back(-1);
+        }
+        node = trie_child[h];
+      }
+      trie_id[node] = static_cast<int32_t>(i);
+    }
+  }
+
   // returns "" or the error message (utils.cpp:99-101)
   std::string build(const std::vector<std::pair<const char *, size_t>> &lines) {
     tokens.clear();
@@ -121,6 +171,7 @@ struct HostVocab {
     }
     std::sort(soft.begin(), soft.end());
     soft.erase(std::unique(soft.begin(), soft.end()), soft.end());
+    build_trie();
   }
 };
 
