@@ -134,6 +134,12 @@ int64_t wp_vocab_token_utf8(const wp_vocab *v, int64_t i, char *buf, size_t cap)
                                  shards a host buffer over, as wp_linear_encode_multi does:
                                  1 (default) = the handle's device only, -1 = all visible GPUs.
                                  Env WP_DEVICES=<count>|all sets the default for new handles. */
+#define WP_OPT_VOCAB_IN_S 10  /* 1: always build S = text . 1 . vocab as linear.cpp:77-101 does.  Default 0:
+                                 the vocabulary stays out of the suffix sort (S = text . 1) and enters
+                                 through the handle's sorted token list and the tokens' code streams;
+                                 the reference's layout is still used for the true suffix array (full
+                                 depth, duplicate lines) and when text or tokens hold U+0000 / U+0001.
+                                 Same token ids either way. */
 int wp_set_option(wp_vocab *v, int option, int64_t value);
 
 /* ---- statistics of the last encode on this handle (for bench.py / roofline) ---- */

@@ -423,3 +423,75 @@ def test_deep_prefix_24mb_ids():
     # (the groups that carry a long token's key are refined until their depth exceeds the longest token)
     assert st["longest_token"] == 512 and st["rounds"] >= 7 and 0 < st["needed_after_round0"] < st["n_total"] // 50
     assert np.array_equal(ids, _oracle_ids_fast(text, vocab))
+
+
+def _ids_both_layouts(text, vocab, label=""):
+    """Default layout (S = text . 1, vocabulary through the per-handle structure) and the reference's
+    S = text . 1 . vocab layout (WP_OPT_VOCAB_IN_S), both depth capped, against the oracle."""
+    exp = O.Vocab(vocab).encode(text, threads=8) if len(text) > 2_000_000 else O.Vocab(vocab).encode(text)
+    a = W.Vocab(vocab)
+    ids = a.encode(text)
+    sa = a.stats()
+    b = W.Vocab(vocab)
+    b.set_option(W.WP_OPT_VOCAB_IN_S, 1)
+    ids_b = b.encode(text)
+    sb = b.stats()
+    assert np.array_equal(ids, exp), label + " text-only layout"
+    assert np.array_equal(ids_b, exp), label + " vocab in S"
+    assert sb["vocab_in_s"] == 1 or len(text) == 0  # (empty input: the path is not entered, linear.cpp:323-325)
+    return sa, sb
+
+
+def test_vocab_structure_layout_equals_reference_layout():
+    """f2: S without the vocabulary.  symbols_n == n_text + 1, same ids as with the vocabulary in S."""
+    text, vocab = synth.english_corpus(4_000_000, seed=51, vocab_size=8000)
+    sa, sb = _ids_both_layouts(text, vocab, "english")
+    assert sa["vocab_in_s"] == 0 and sa["n_total"] == sa["n_text"] + 1 and sb["n_total"] > sb["n_text"] + 1000
+    assert 0 <= sa["needed_after_round0"] < sa["n_total"] // 20
+    text, vocab = synth.multilingual_corpus(3_000_000, seed=52, vocab_size=20000)
+    sa, _ = _ids_both_layouts(text, vocab, "multilingual")
+    assert sa["vocab_in_s"] == 0 and sa["alphabet"] > 255
+    text, vocab = synth.deep_prefix_corpus(3_000_000, seed=53)
+    sa, sb = _ids_both_layouts(text, vocab, "deep")
+    assert sa["vocab_in_s"] == 0 and sa["rounds"] >= 5 and sb["n_total"] - sa["n_total"] > 10_000_000
+    for case in _load("reference_tests_cpp.json") + _load("survey_probed_cases.json"):
+        t = bytes.fromhex(case["text_hex"])
+        vc = [bytes.fromhex(w) for w in case["vocab_hex"]]
+        _ids_both_layouts(t, vc, case.get("name", "vector"))
+    rng = random.Random(606)
+    alpha = "ab-, .c中"
+    done = 0
+    while done < 400:
+        nt = rng.randint(1, 9)
+        vocab = set()
+        while len(vocab) < nt:
+            w = "".join(rng.choice(alpha) for _ in range(rng.randint(1, 24 if done % 7 == 0 else 5)))
+            if rng.random() < 0.4:
+                w = "##" + w
+            vocab.add(w)
+        vocab = sorted(vocab)
+        rng.shuffle(vocab)
+        # (long tokens and long repetitive texts: tokens whose code stream exceeds the 63-bit key)
+        text = "".join(rng.choice(alpha if done % 3 else "ab") for _ in range(rng.randint(0, 60) if done % 5 else rng.randint(300, 4000)))
+        if done % 11 == 0 and vocab:
+            text += " " + vocab[0].lstrip("#") * 3
+        try:
+            O.Vocab(vocab)
+        except O.OracleError:
+            continue
+        _ids_both_layouts(text, vocab, repr((text[:60], vocab)))
+        done += 1
+
+
+def test_low_code_points_use_the_reference_layout():
+    """U+0000 / U+0001 in the text or in a token sort around the separator (code point 1, linear.cpp:92):
+    those inputs keep S = text . 1 . vocab."""
+    vocab = ["a", "##b", "ab", "[UNK]"]
+    for text in (b"ab a\x01b ab", b"ab\x00 ab"):
+        gv = W.Vocab(vocab)
+        assert np.array_equal(gv.encode(text), O.Vocab(vocab).encode(text))
+        assert gv.stats()["vocab_in_s"] == 1
+    vocab = ["a", "##b", "a\x01", "ab"]
+    gv = W.Vocab(vocab)
+    assert np.array_equal(gv.encode(b"ab a\x01 ab"), O.Vocab(vocab).encode(b"ab a\x01 ab"))
+    assert gv.stats()["vocab_in_s"] == 1

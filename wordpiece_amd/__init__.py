@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WP_LIB") or os.path.join(_HERE, "libwordpiece_amd.so")
 
 WP_OPT_FULL_DEPTH, WP_OPT_DEVICE, WP_OPT_KEEP_DEBUG, WP_OPT_STAGE_TIMING, WP_OPT_LCP_KASAI = 1, 2, 3, 4, 5
-WP_OPT_FUSED_RERANK, WP_OPT_COVER_ANCHORS, WP_OPT_ARENA_GUARD, WP_OPT_DEVICES = 6, 7, 8, 9
+WP_OPT_FUSED_RERANK, WP_OPT_COVER_ANCHORS, WP_OPT_ARENA_GUARD, WP_OPT_DEVICES, WP_OPT_VOCAB_IN_S = 6, 7, 8, 9, 10
 
 # every symbol include/wordpiece_amd.h declares (checked by the CPU test-suite)
 ABI_SYMBOLS = [

@@ -22,8 +22,12 @@
 
 namespace wp {
 
+// 40 bits = 5 radix passes.  With the round-0 pruning (prune.h) ties cost next to nothing — only the
+// groups that carry a long token's key go on — so fewer key bits are a plain saving of passes until the
+// needed groups grow: measured on the 100 MB bench shard, ms per step / entries in round 1:
+// 63 bits 11.3 / 12 k, 56: 10.6 / 60 k, 48: 10.1 / 0.25 M, 40: 9.5 / 0.8 M, 32: 9.6 / 3.0 M, 24: 9.9 / 5.6 M.
 #ifndef WP_KEY_BITS
-#define WP_KEY_BITS 63
+#define WP_KEY_BITS 40
 #endif
 constexpr int kKeyBits = WP_KEY_BITS;  // bits of the codeword stream kept in a round-0 key (<= 63)
 constexpr int kMaxCodeLen = 12;  // decode table: 2^12 entries (first codeword length of a 12-bit window)

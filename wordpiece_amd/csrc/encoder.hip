@@ -180,6 +180,7 @@ struct wp_vocab {
   int device = -1;
   bool full_depth = false, keep_debug = false, stage_timing = false, lcp_kasai = false, fused_rerank = false, cover_anchors = false;
   bool arena_guard = false;
+  bool vocab_in_s = false;  // WP_OPT_VOCAB_IN_S: always the reference's S = text . 1 . vocab layout
   int n_devices = 1;  // WP_OPT_DEVICES: GPUs wp_linear_encode shards a host buffer over (-1: all visible)
   wp_stats stats{};
   ~wp_vocab();
@@ -280,7 +281,7 @@ static void fetch_scalars(Context *c, int count) {
 template <typename SymT>
 static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena &ar, Arena &aa, const uint8_t *d_text,
                               size_t nbytes, const uint32_t *d_tile_prefix, size_t n_text, size_t n, uint32_t *d_cps,
-                              uint8_t *d_cls, int bits, size_t *n_ids_out);
+                              uint8_t *d_cls, int bits, bool text_only, size_t *n_ids_out);
 
 static bool env_flag(const char *name) {
   const char *e = getenv(name);
@@ -332,21 +333,33 @@ static void encode_on_device(const wp_vocab *v, Context *c, const uint8_t *d_tex
                      reinterpret_cast<unsigned long long *>(c->d_scalars + 2), c->d_used);
   device_exclusive_scan(d_tile_cnt, d_tile_cnt, dec_tiles, d_cnt_tmp, c->d_scalars + 0, st, nullptr,
                         reinterpret_cast<unsigned long long *>(c->d_scalars + 14));
+  // does the text itself hold code point 0 or 1 (the separator)?  (read before the vocab marks its symbols)
+  WP_HIP(hipMemcpyAsync(c->d_scalars + 20, c->d_used, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(mark_used_kernel, dim3(cdiv(std::max<size_t>(hv.stream.size(), 1), kBlock)), dim3(kBlock), 0,
                      st, c->d_stream, hv.stream.size(), c->d_used);
   device_exclusive_scan(c->d_used, c->d_lut, kCpTableSize, c->d_scan_tmp, c->d_scalars + 1, st);
   WP_LAUNCH_CHECK();
-  fetch_scalars(c, 16);
+  fetch_scalars(c, 22);
   unsigned long long n_text64;
   std::memcpy(&n_text64, c->h_scalars + 14, sizeof(n_text64));
   if (n_text64 + 1 + hv.stream.size() > 2000000000ull) throw std::length_error("64bit not implemented");  // linear.cpp:104-106
   const size_t n_text = c->h_scalars[0];
+  // Layout of S.  The reference concatenates the whole vocabulary behind the text in every call and batch
+  // (linear.cpp:77-101, 333, 347, 367).  Here the vocabulary normally stays out of the suffix sort: S = text . 1,
+  // and the tokens come in through their code streams (prune.h).  The reference's layout is kept for the true
+  // suffix array (full depth, duplicate vocab lines), for texts or tokens that hold the code points 0 / 1
+  // (they sort around the separator), and on request (WP_OPT_VOCAB_IN_S).
+  static const bool env_vocab_in_s = env_flag("WP_VOCAB_IN_S");
+  const bool full_sa = v->full_depth || hv.n_dup_eligible > 0 || v->lcp_kasai;
+  const bool text_only = !full_sa && !v->vocab_in_s && !env_vocab_in_s && !hv.low_cp && c->h_scalars[20] == 0 &&
+                         c->h_scalars[21] == 0 && !env_flag("WP_NO_PRUNE");
+  S.vocab_in_s = text_only ? 0 : 1;
   const uint32_t sigma = c->h_scalars[1];
   unsigned long long dropped;
   std::memcpy(&dropped, c->h_scalars + 2, sizeof(dropped));
   if (dropped != 0) std::cerr << "WARNING Input contains invalid unicode characters." << std::endl;
 
-  const size_t n = n_text + 1 + hv.stream.size();  // total_length, linear.cpp:77-82
+  const size_t n = n_text + 1 + (text_only ? 0 : hv.stream.size());  // total_length, linear.cpp:77-82
   S.n_text = static_cast<int64_t>(n_text);
   S.n_total = static_cast<int64_t>(n);
   S.alphabet = sigma;
@@ -356,16 +369,18 @@ static void encode_on_device(const wp_vocab *v, Context *c, const uint8_t *d_tex
   const int bits = std::max(1, bit_length(sigma));  // symbols are 1..sigma, 0 = past the end
   Arena ab(&c->b_buf, guard);
   if (sigma <= 255) {
-    run_sa_and_beyond<uint8_t>(v, c, S, ab, aa, d_text, nbytes, d_tile_cnt, n_text, n, d_cps, d_cls, bits, n_ids_out);
+    run_sa_and_beyond<uint8_t>(v, c, S, ab, aa, d_text, nbytes, d_tile_cnt, n_text, n, d_cps, d_cls, bits, text_only,
+                               n_ids_out);
   } else {
-    run_sa_and_beyond<uint32_t>(v, c, S, ab, aa, d_text, nbytes, d_tile_cnt, n_text, n, d_cps, d_cls, bits, n_ids_out);
+    run_sa_and_beyond<uint32_t>(v, c, S, ab, aa, d_text, nbytes, d_tile_cnt, n_text, n, d_cps, d_cls, bits, text_only,
+                                n_ids_out);
   }
 }
 
 template <typename SymT>
 static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena &ar, Arena &aa, const uint8_t *d_text,
                               size_t nbytes, const uint32_t *d_tile_prefix, size_t n_text, size_t n, uint32_t *d_cps,
-                              uint8_t *d_cls, int bits, size_t *n_ids_out) {
+                              uint8_t *d_cls, int bits, bool text_only, size_t *n_ids_out) {
   hipStream_t st = c->stream;
   hipStream_t st2 = c->stream2;
   // st2 starts after everything queued on st so far / st continues after everything queued on st2
@@ -397,7 +412,8 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   static const bool env_no_digit_bytes = env_flag("WP_NO_DIGIT_BYTES");
   const bool use_digit_bytes = !env_no_digit_bytes && kRadixBits <= 8 && n > kRadixSmallN;
   SymT *d_sym = nullptr;
-  uint8_t *DG0 = nullptr, *DG1 = nullptr, *d_need = nullptr;
+  uint8_t *DG0 = nullptr, *DG1 = nullptr, *d_need = nullptr, *d_rng_long = nullptr;
+  uint32_t *d_rng_lo = nullptr, *d_rng_hi = nullptr;
   uint32_t *d_claim = nullptr;
   size_t claim_size = 1024;  // hash table of claimed key ranges (prune.h): a power of two >= 2 M
   while (claim_size < 2 * static_cast<size_t>(std::max(M, 1))) claim_size *= 2;
@@ -434,7 +450,10 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     AS0 = ar.take<uint32_t>(n);
     AS1 = ar.take<uint32_t>(n);
     AG = ar.take<uint32_t>(n);
-    d_sa = (v->keep_debug || v->lcp_kasai) ? ar.take<uint32_t>(n) : nullptr;
+    d_sa = (v->keep_debug || v->lcp_kasai || text_only) ? ar.take<uint32_t>(n) : nullptr;
+    d_rng_lo = ar.take<uint32_t>(M + 1);
+    d_rng_hi = ar.take<uint32_t>(M + 1);
+    d_rng_long = ar.take<uint8_t>(M + 1);
     d_rank = ar.take<RankEntry>(n);
     AD0 = ar.take<uint32_t>(n);
     AD1 = ar.take<uint32_t>(n);
@@ -551,8 +570,8 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   // ---------------- suffix array by prefix doubling ----------------
   // round 0 only keeps the tied groups that carry the key of a long eligible token (prune.h)
   static const bool env_no_prune = env_flag("WP_NO_PRUNE");
-  const bool prune = !full && !env_no_prune && M > 0;
-  DepthRule rule{need_depth, full ? 1 : 0, nullptr};
+  const bool prune = !full && !env_no_prune && (M > 0 || text_only);
+  DepthRule rule{need_depth, full ? 1 : 0, nullptr, 0};
   // after every rerank: classify the new groups (large ones take the global path next round)
   // (runs on the side stream, next to the rank scatter)
   auto classify_groups = [&](size_t list_len) {
@@ -598,11 +617,15 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   if (prune) {
     WP_HIP(hipMemsetAsync(d_need, 0, n, st));
     WP_HIP(hipMemsetAsync(d_claim, 0xff, claim_size * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(need_groups_kernel, dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)), dim3(kBlock), 0, st, keys, n,
-                       c->d_stream, c->d_elig_start, c->d_elig_info, M, c->d_lut, dcode, d_claim,
-                       static_cast<uint32_t>(claim_size - 1), d_need,
-                       reinterpret_cast<unsigned long long *>(c->d_scalars + 18));
+    if (M > 0) {  // (no eligible token at all: every tied group retires)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(need_groups_kernel<SymT>), dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)),
+                         dim3(kBlock), 0, st, keys, vals, n, d_sym, c->d_stream, c->d_elig_start, c->d_elig_info, M,
+                         c->d_lut, dcode, d_claim, static_cast<uint32_t>(claim_size - 1), d_need,
+                         reinterpret_cast<unsigned long long *>(c->d_scalars + 18), text_only ? d_rng_lo : nullptr,
+                         d_rng_hi, d_rng_long);
+    }
     rule.need_map = d_need;
+    rule.sa_needed_only = (text_only && !v->keep_debug) ? 1 : 0;
   }
   uint32_t *slots = AS0, *other_slots = AS1;
   uint32_t *adep = AD0, *other_dep = AD1;
@@ -770,27 +793,40 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   {
     const size_t vocab_base = n_text + 1;
     uint32_t *mslot = d_mslot0, *midx = d_midx0;
-    if (M > 0) {
-      hipLaunchKernelGGL(mark_slots_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, c->d_elig_start, M,
-                         vocab_base, d_rank, d_mslot0, d_midx0);
-      int mc = radix_sort_pairs<uint32_t>(d_mslot0, d_midx0, d_mslot1, d_midx1, M, 0, bit_length(n), d_radix_tmp,
-                                          radix_words, st, nullptr);
-      mslot = mc ? d_mslot1 : d_mslot0;
-      midx = mc ? d_midx1 : d_midx0;
-      hipLaunchKernelGGL(mark_gather_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, midx, M, c->d_elig_id,
-                         c->d_elig_info, d_mid, d_minfo);
-    }
-    hipLaunchKernelGGL(tile_mlo_kernel, dim3(cdiv(sl_tiles + 1, kBlock)), dim3(kBlock), 0, st, mslot, M, n, sl_tiles,
-                       d_tile_mlo);
-    hipLaunchKernelGGL(sl_summary_kernel, dim3(sl_tiles), dim3(kBlock), 0, st, d_lcp, n, mslot, d_minfo, d_tile_mlo,
-                       d_tmin_f, d_tmin_b, d_rf, d_rb);
-    hipLaunchKernelGGL(sl_group_min_kernel, dim3(cdiv(static_cast<size_t>(sl_groups) * kWave, kBlock)), dim3(kBlock),
-                       0, st, d_tmin_f, d_tmin_b, sl_tiles, sl_groups, d_gmin_f, d_gmin_b);
-    mv = MarkView{mslot, d_mid, d_minfo, d_rf, d_rb, M, d_cover_f, d_cover_b};
-    if (M > 0) {
-      hipLaunchKernelGGL(sl_reach_global_kernel, dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)), dim3(kBlock), 0,
-                         st, d_lcp, n, sl_tiles, sl_groups, mslot, d_minfo, M, d_tmin_f, d_tmin_b, d_gmin_f, d_gmin_b,
-                         d_rf, d_rb);
+    if (text_only) {
+      // S = text . 1: the reach of every token is its range in the sorted keys (prune.h); long tokens are
+      // narrowed inside their refined group.  The marks arrive sorted (tokens in lexicographic order).
+      if (M > 0) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(long_token_range_kernel<SymT>), dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, d_sa,
+                           d_sym, n, c->d_stream, c->d_elig_start, c->d_elig_info, M, c->d_lut, d_rng_lo, d_rng_hi,
+                           d_rng_long);
+        hipLaunchKernelGGL(virtual_marks_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, d_rng_lo, d_rng_hi, M,
+                           c->d_elig_id, c->d_elig_info, d_mslot0, d_mid, d_minfo, d_rf, d_rb);
+      }
+      mv = MarkView{mslot, d_mid, d_minfo, d_rf, d_rb, M, d_cover_f, d_cover_b};
+    } else {
+      if (M > 0) {
+        hipLaunchKernelGGL(mark_slots_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, c->d_elig_start, M,
+                           vocab_base, d_rank, d_mslot0, d_midx0);
+        int mc = radix_sort_pairs<uint32_t>(d_mslot0, d_midx0, d_mslot1, d_midx1, M, 0, bit_length(n), d_radix_tmp,
+                                            radix_words, st, nullptr);
+        mslot = mc ? d_mslot1 : d_mslot0;
+        midx = mc ? d_midx1 : d_midx0;
+        hipLaunchKernelGGL(mark_gather_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, midx, M, c->d_elig_id,
+                           c->d_elig_info, d_mid, d_minfo);
+      }
+      hipLaunchKernelGGL(tile_mlo_kernel, dim3(cdiv(sl_tiles + 1, kBlock)), dim3(kBlock), 0, st, mslot, M, n, sl_tiles,
+                         d_tile_mlo);
+      hipLaunchKernelGGL(sl_summary_kernel, dim3(sl_tiles), dim3(kBlock), 0, st, d_lcp, n, mslot, d_minfo, d_tile_mlo,
+                         d_tmin_f, d_tmin_b, d_rf, d_rb);
+      hipLaunchKernelGGL(sl_group_min_kernel, dim3(cdiv(static_cast<size_t>(sl_groups) * kWave, kBlock)), dim3(kBlock),
+                         0, st, d_tmin_f, d_tmin_b, sl_tiles, sl_groups, d_gmin_f, d_gmin_b);
+      mv = MarkView{mslot, d_mid, d_minfo, d_rf, d_rb, M, d_cover_f, d_cover_b};
+      if (M > 0) {
+        hipLaunchKernelGGL(sl_reach_global_kernel, dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)), dim3(kBlock), 0,
+                           st, d_lcp, n, sl_tiles, sl_groups, mslot, d_minfo, M, d_tmin_f, d_tmin_b, d_gmin_f, d_gmin_b,
+                           d_rf, d_rb);
+      }
     }
     if (M > 0) {
       hipLaunchKernelGGL(mark_cover_kernel, dim3(4), dim3(kCoverThreads), 0, st, d_minfo, d_rf, d_rb, M, d_cover_f,
@@ -1232,6 +1268,7 @@ int wp_set_option(wp_vocab *v, int option, int64_t value) {
     case WP_OPT_FUSED_RERANK: v->fused_rerank = value != 0; return WP_OK;
     case WP_OPT_COVER_ANCHORS: v->cover_anchors = value != 0; return WP_OK;
     case WP_OPT_ARENA_GUARD: v->arena_guard = value != 0; return WP_OK;
+    case WP_OPT_VOCAB_IN_S: v->vocab_in_s = value != 0; return WP_OK;
     case WP_OPT_DEVICES: v->n_devices = value < 0 ? -1 : static_cast<int>(std::max<int64_t>(value, 1)); return WP_OK;
   }
   g_last_error = "unknown option";

@@ -23,9 +23,10 @@ namespace wp {
 constexpr uint32_t kClaimEmpty = 0xffffffffu;
 
 // first kKeyBits bits of the code stream of token symbols cps[0..len) (code points -> dense symbols
-// through lut); returns false if the whole stream fits into the key (the token is not "long")
+// through lut), left aligned; bits_out = bits of the stream inside the key (<= kKeyBits); returns true
+// if the stream is longer than the key (a "long" token)
 __device__ inline bool token_key(const uint32_t *__restrict__ cps, uint32_t len, const uint32_t *__restrict__ lut_excl,
-                                 const DevCode &code, uint64_t &key_out) {
+                                 const DevCode &code, uint64_t &key_out, int &bits_out) {
   const int ub = code.uniform_bits > 0 ? code.uniform_bits : 0;
   const int lo = code.uniform_bits < 0 ? -code.uniform_bits : 0;
   const uint32_t lomask = (1u << lo) - 1u;
@@ -55,37 +56,95 @@ __device__ inline bool token_key(const uint32_t *__restrict__ cps, uint32_t len,
     used += l;
   }
   key_out = key << (kKeyBits - used);
+  bits_out = used;
   return overflow;
 }
 
-__global__ __launch_bounds__(kBlock) void need_groups_kernel(const uint64_t *__restrict__ keys, size_t n,
+__device__ __forceinline__ size_t key_lower_bound(const uint64_t *__restrict__ keys, size_t n, uint64_t key) {
+  size_t lo = 0, hi = n;
+  while (lo < hi) {
+    const size_t md = (lo + hi) >> 1;
+    if (keys[md] < key) lo = md + 1; else hi = md;
+  }
+  return lo;
+}
+
+// suffix at text position v against the token (dense symbols through lut): -1 / +1 = the suffix sorts
+// before / behind every string that starts with the token, 0 = the token is a prefix of the suffix
+template <typename SymT>
+__device__ __forceinline__ int suffix_vs_token(const SymT *__restrict__ sym, size_t n, size_t v,
+                                               const uint32_t *__restrict__ cps, uint32_t len,
+                                               const uint32_t *__restrict__ lut_excl) {
+  for (uint32_t j = 0; j < len; j++) {
+    const uint32_t a = v + j < n ? static_cast<uint32_t>(sym[v + j]) : 0u;
+    const uint32_t b = lut_excl[cps[j]] + 1u;
+    if (a != b) return a < b ? -1 : 1;
+  }
+  return 0;
+}
+
+// Text-only layout (S = text . 1, the vocabulary kept out of the suffix sort): the reach of a token
+// — the SA slots of the suffixes it is a prefix of, what the reference's stack pops delimit
+// (linear.cpp:161-189) — is the equal range of its code stream in the sorted keys.  rng_lo/rng_hi
+// (nullptr: not wanted) receive it for tokens whose stream fits the key; for long tokens they receive
+// the group that carries the token's key (refined by the rounds, then narrowed by
+// long_token_range_kernel) and rng_long[m] = 1.
+template <typename SymT>
+__global__ __launch_bounds__(kBlock) void need_groups_kernel(const uint64_t *__restrict__ keys,
+                                                             const uint32_t *__restrict__ vals, size_t n,
+                                                             const SymT *__restrict__ sym,
                                                              const uint32_t *__restrict__ vocab_cps,
                                                              const uint32_t *__restrict__ tok_start,
                                                              const uint32_t *__restrict__ tok_info, int M,
                                                              const uint32_t *__restrict__ lut_excl, DevCode code,
                                                              uint32_t *__restrict__ claim, uint32_t claim_mask,
                                                              uint8_t *__restrict__ need,
-                                                             unsigned long long *__restrict__ n_needed) {
+                                                             unsigned long long *__restrict__ n_needed,
+                                                             uint32_t *__restrict__ rng_lo, uint32_t *__restrict__ rng_hi,
+                                                             uint8_t *__restrict__ rng_long) {
   const int m = static_cast<int>((static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6);
   const int lane = lane_id();
   if (m >= M) return;
   uint64_t key = 0;
+  int bits = 0;
   const uint32_t len = tok_info[m] & 0x0fffffffu;
-  if (!token_key(vocab_cps + tok_start[m], len, lut_excl, code, key)) return;  // wave-uniform
-  // equal range of `key` in the sorted keys (every lane runs the same search: the loads broadcast)
-  size_t lo = 0, hi = n;
-  while (lo < hi) {
-    const size_t md = (lo + hi) >> 1;
-    if (keys[md] < key) lo = md + 1; else hi = md;
+  const uint32_t *cps = vocab_cps + tok_start[m];
+  const bool is_long = token_key(cps, len, lut_excl, code, key, bits);  // wave-uniform
+  if (!is_long) {
+    if (!rng_lo) return;
+    // every lane runs the same searches: the loads broadcast
+    const size_t lb = key_lower_bound(keys, n, key);
+    const uint64_t step = 1ull << (kKeyBits - bits);
+    const uint64_t above = key + step;  // first key that no longer starts with the stream
+    const size_t ubd = (bits == 0 || (above >> kKeyBits) != 0) ? n : key_lower_bound(keys, n, above);
+    if (lane == 0) {
+      rng_lo[m] = static_cast<uint32_t>(lb);
+      rng_hi[m] = static_cast<uint32_t>(ubd);
+      rng_long[m] = 0;
+    }
+    return;
   }
-  const size_t first = lo;
-  hi = n;
-  while (lo < hi) {
-    const size_t md = (lo + hi) >> 1;
-    if (keys[md] <= key) lo = md + 1; else hi = md;
+  const size_t first = key_lower_bound(keys, n, key);
+  const size_t last = key_lower_bound(keys, n, key + 1);
+  if (last - first < 2) {  // no such suffix, or a single one: nothing to refine
+    if (rng_lo && lane == 0) {
+      size_t lb = first, ubd = first;
+      if (last > first) {
+        const int cmp = suffix_vs_token(sym, n, vals[first], cps, len, lut_excl);
+        lb = cmp < 0 ? first + 1 : first;
+        ubd = cmp <= 0 ? first + 1 : first;
+      }
+      rng_lo[m] = static_cast<uint32_t>(lb);
+      rng_hi[m] = static_cast<uint32_t>(ubd);
+      rng_long[m] = 0;
+    }
+    return;
   }
-  const size_t last = lo;
-  if (last - first < 2) return;  // no such suffix, or a singleton: nothing to refine
+  if (rng_lo && lane == 0) {
+    rng_lo[m] = static_cast<uint32_t>(first);
+    rng_hi[m] = static_cast<uint32_t>(last);
+    rng_long[m] = 1;
+  }
   // several tokens share a key (all long prefixes of one word): the first to claim the range fills it
   int won = 0;
   if (lane == 0) {
@@ -104,6 +163,59 @@ __global__ __launch_bounds__(kBlock) void need_groups_kernel(const uint64_t *__r
   won = __shfl(won, 0, kWave);
   if (!won) return;
   for (size_t k = first + lane; k < last; k += kWave) need[k] = 1;
+}
+
+// After the rounds: the group [rng_lo, rng_hi) of a long token is sorted by more symbols than the token
+// has; narrow it to the suffixes the token is a prefix of (sa: slot -> text position, kept for the slots
+// of the needed groups).
+template <typename SymT>
+__global__ __launch_bounds__(kBlock) void long_token_range_kernel(const uint32_t *__restrict__ sa,
+                                                                  const SymT *__restrict__ sym, size_t n,
+                                                                  const uint32_t *__restrict__ vocab_cps,
+                                                                  const uint32_t *__restrict__ tok_start,
+                                                                  const uint32_t *__restrict__ tok_info, int M,
+                                                                  const uint32_t *__restrict__ lut_excl,
+                                                                  uint32_t *__restrict__ rng_lo,
+                                                                  uint32_t *__restrict__ rng_hi,
+                                                                  const uint8_t *__restrict__ rng_long) {
+  const int m = blockIdx.x * kBlock + threadIdx.x;
+  if (m >= M || !rng_long[m]) return;
+  const uint32_t len = tok_info[m] & 0x0fffffffu;
+  const uint32_t *cps = vocab_cps + tok_start[m];
+  const uint32_t glo = rng_lo[m], ghi = rng_hi[m];
+  uint32_t lo = glo, hi = ghi;
+  while (lo < hi) {  // first slot whose suffix is not before the token's range
+    const uint32_t md = lo + ((hi - lo) >> 1);
+    if (suffix_vs_token(sym, n, sa[md], cps, len, lut_excl) < 0) lo = md + 1; else hi = md;
+  }
+  const uint32_t lb = lo;
+  hi = ghi;
+  while (lo < hi) {  // first slot behind it
+    const uint32_t md = lo + ((hi - lo) >> 1);
+    if (suffix_vs_token(sym, n, sa[md], cps, len, lut_excl) <= 0) lo = md + 1; else hi = md;
+  }
+  rng_lo[m] = lb;
+  rng_hi[m] = lo;
+}
+
+// marks of the text-only layout for the step functions of scanline.h: a token stands in front of the
+// first slot of its range and covers [lo, hi) in the left-to-right sense only
+__global__ __launch_bounds__(kBlock) void virtual_marks_kernel(const uint32_t *__restrict__ rng_lo,
+                                                               const uint32_t *__restrict__ rng_hi, int M,
+                                                               const int32_t *__restrict__ tok_id,
+                                                               const uint32_t *__restrict__ tok_info,
+                                                               uint32_t *__restrict__ mslot, int32_t *__restrict__ mid,
+                                                               uint32_t *__restrict__ minfo,
+                                                               int32_t *__restrict__ reach_fwd,
+                                                               int32_t *__restrict__ reach_bwd) {
+  const int m = blockIdx.x * kBlock + threadIdx.x;
+  if (m >= M) return;
+  const uint32_t lo = rng_lo[m];
+  mslot[m] = lo;
+  mid[m] = tok_id[m];
+  minfo[m] = tok_info[m];
+  reach_fwd[m] = static_cast<int32_t>(max(rng_hi[m], lo));
+  reach_bwd[m] = static_cast<int32_t>(lo);  // nothing in front of the mark is covered
 }
 
 }  // namespace wp

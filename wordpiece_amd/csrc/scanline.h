@@ -317,8 +317,10 @@ __global__ __launch_bounds__(kBlock) void piece_starts_kernel(MarkView mv, size_
   if (m >= mv.M) return;
   const uint32_t last = static_cast<uint32_t>(n - 1);
   uint32_t *o = pstart + kStepsPerMark * static_cast<size_t>(m);
-  o[0] = static_cast<uint32_t>(mv.reach_bwd[m] + 1);
-  o[1] = mv.mslot[m];
+  // (marks of the text-only layout stand in front of slot `mslot`, which may be n: every start is clamped
+  // to the last slot, so that the list sorts within bit_length(n) bits and every start is a real slot)
+  o[0] = min(static_cast<uint32_t>(mv.reach_bwd[m] + 1), last);
+  o[1] = min(mv.mslot[m], last);
   o[2] = min(mv.mslot[m] + 1u, last);
   o[3] = min(static_cast<uint32_t>(mv.reach_fwd[m]), last);
 }

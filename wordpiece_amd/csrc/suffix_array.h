@@ -40,6 +40,7 @@ struct DepthRule {
   // round 0, depth-capped mode (prune.h): need_map[k] != 0 iff sorted position k lies in a group that
   // carries the key of an eligible token longer than the key; all other groups retire at once
   const uint8_t *need_map;
+  int sa_needed_only;  // round 0: keep SA entries only for the slots of needed groups (text-only layout)
 };
 
 template <bool ROUND0>
@@ -359,7 +360,7 @@ __device__ __forceinline__ void rr_second_half(const RrTile &T, const uint64_t *
                                                uint32_t *__restrict__ nslots, uint32_t *__restrict__ nvals,
                                                uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep,
                                                uint32_t *__restrict__ ghead, uint32_t *__restrict__ gdepth,
-                                               uint32_t *__restrict__ gd) {
+                                               uint32_t *__restrict__ gd, const DepthRule &rule) {
   const int lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
   // rounds >= 1: does the group of the carried head continue the old group of the entry before it?
@@ -384,7 +385,9 @@ __device__ __forceinline__ void rr_second_half(const RrTile &T, const uint64_t *
       const uint32_t v = vals[k];
       const uint32_t x = ROUND0 ? static_cast<uint32_t>(k) : slots[k];
       const uint32_t head_slot = ROUND0 ? static_cast<uint32_t>(head) : slots[head];
-      if (sa) sa[x] = v;  // the suffix array itself is only kept for debug fetches / the Kasai kernel
+      // the suffix array itself is only kept for debug fetches / the Kasai kernel, and (text-only layout)
+      // for the slots of the groups whose long tokens are located in it afterwards
+      if (sa && !(ROUND0 && rule.sa_needed_only && !rule.need_map[k])) sa[x] = v;
       // new rank entry of suffix v, scattered to the rank table afterwards.  In rounds >= 1 the
       // first subgroup of an old group keeps its rank (its head is the old head): left unchanged.
       bool changed = true;
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     head1 = max(head1, s_last[i]);
   }
   rr_second_half<SymT, ROUND0>(T, keys, m, wave_base, ea, eh, head1, vals, slots, adep, sym, n, s_fl, uniform_bits, sa,
-                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, nullptr);
+                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, nullptr, rule);
 }
 
 // ---- single-pass form: the two passes fused with a chained scan ----------------------------------
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(kBlock) void rerank_fused_kernel(
     head1 = max(head1, s_last[i]);
   }
   rr_second_half<SymT, ROUND0>(T, keys, m, wave_base, ea, eh, head1, vals, slots, adep, sym, n, s_fl, uniform_bits, sa,
-                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, ROUND0 ? nullptr : gd);
+                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, ROUND0 ? nullptr : gd, rule);
 }
 
 __global__ __launch_bounds__(kBlock) void gdepth_store_kernel(const uint32_t *__restrict__ gd,

@@ -141,6 +141,9 @@ struct HostVocab {
     return "";
   }
 
+  bool low_cp = false;  // some token holds code point 0 or 1 (1 is the separator of S, linear.cpp:92,99):
+                        // such vocabularies always go through the reference's S = text . 1 . vocab layout
+
   void derive() {
     stream.clear();
     elig_start.clear();
@@ -150,15 +153,20 @@ struct HostVocab {
     soft.clear();
     longest = 1;
     n_dup_eligible = 0;
+    low_cp = false;
     std::map<std::pair<bool, std::vector<uint32_t>>, int> seen;
+    std::vector<uint32_t> starts(tokens.size());
+    std::vector<size_t> elig;
     for (size_t i = 0; i < tokens.size(); i++) {
       const HostToken &t = tokens[i];
       longest = std::max<int64_t>(longest, static_cast<int64_t>(t.word.size()));
       tok_len.push_back(static_cast<int32_t>(t.word.size()));
+      starts[i] = static_cast<uint32_t>(stream.size());
+      for (uint32_t c : t.word) {
+        if (c <= 1) low_cp = true;
+      }
       if (!t.is_special && !t.is_malformed) {  // linear.cpp:179
-        elig_start.push_back(static_cast<uint32_t>(stream.size()));
-        elig_id.push_back(static_cast<int32_t>(i));
-        elig_info.push_back(static_cast<uint32_t>(t.word.size()) | (t.is_prefix ? 0u : 1u) << 30);
+        elig.push_back(i);
         if (++seen[{t.is_prefix, t.word}] > 1) n_dup_eligible++;
         if (t.word.size() > 1) {
           for (uint32_t c : t.word) {
@@ -168,6 +176,15 @@ struct HostVocab {
       }
       stream.insert(stream.end(), t.word.begin(), t.word.end());
       stream.push_back(1);
+    }
+    // eligible tokens in lexicographic order of their words (a proper prefix first): the order of their
+    // suffixes in S, so that the marks of the text-only layout come out sorted by slot
+    std::stable_sort(elig.begin(), elig.end(), [&](size_t a, size_t b) { return tokens[a].word < tokens[b].word; });
+    for (size_t i : elig) {
+      const HostToken &t = tokens[i];
+      elig_start.push_back(starts[i]);
+      elig_id.push_back(static_cast<int32_t>(i));
+      elig_info.push_back(static_cast<uint32_t>(t.word.size()) | (t.is_prefix ? 0u : 1u) << 30);
     }
     std::sort(soft.begin(), soft.end());
     soft.erase(std::unique(soft.begin(), soft.end()), soft.end());
