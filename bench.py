@@ -3,16 +3,20 @@
 
 A step = one pass of the hot path (UTF-8 decode -> S build -> suffix array + LCP by prefix
 doubling -> scanlines -> greedy walk -> id stream) over one shard per GPU, the shard already
-resident in HBM and the ids left in HBM.  Workload = BASELINE.json configs[1]: a 100 MB
-English-shaped shard with a 29k-line BERT-like vocabulary (synthetic, SURVEY.md §8d config 2;
-enwiki and bert-base-cased vocab.txt are not available offline).  With N > 1 every rank
-tokenizes its own shard (weak scaling, no collective on the data path) and the token ids are
-gathered to rank 0 over RCCL at the end of every step, as the north star prescribes.
+resident in HBM and the ids left in HBM (`value`).  Default workload = BASELINE.json configs[1]:
+a 100 MB English-shaped shard with a 29k-line BERT-like vocabulary (synthetic, SURVEY.md §8d
+config 2; enwiki and bert-base-cased vocab.txt are not available offline).  `--config 3|4|5`
+selects the other single-GPU-sized configurations (1 GB mixed scripts, one 1.25 GB shard of the
+10 GB run per GPU, 1 GB deep-prefix stress).  With N > 1 every rank tokenizes its own shard (weak
+scaling, no collective on the data path) and the token ids are gathered to rank 0 over RCCL at the end
+of every step, as the north star prescribes.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+Also reported on rank 0 at N = 1: `host_to_host` (SURVEY §8d's metric proper: host-resident text to
+host-resident ids through wp_linear_encode, upload and download included), the sibling `fast` path's
+device rate, the roofline of the dominant kernel, the SA/LCP stage against the HBM peak and the CPU
+baseline.  Prints ONE JSON line on rank 0; exits non-zero if the ids differ from the CPU port's.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -29,9 +33,19 @@ from wordpiece_amd import synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
 RADIX_BYTES_PER_ELEM = 24  # one radix pass reads and writes a 12-byte (key, index) record
-
+# SA/LCP stage, algorithmic bytes per symbol besides the radix passes:
+SPLIT_BYTES = 30       # round-0 split: keys 8 + need map 1 (count pass); keys 8 + index 4 + need map 1 read, rank 4 + LCP 4 written
+RANK_STORE_BYTES = 32  # destination partition (4 read; 8 read + 8 written) + scatter (8 read, 4 written)
+ROUND_BYTES = 110      # rounds >= 1, per list entry: LDS sort 28 + split 50 + rank store 32
 
 _DevView = W.DeviceIds  # zero-copy torch view of a device buffer owned by the library
+
+CONFIGS = {
+    2: ("english", 100.0, 29000, "configs[1]: %.0f MB English-shaped synthetic shard per GPU (SURVEY 8d config 2)"),
+    3: ("multilingual", 1000.0, 120000, "configs[2]: %.0f MB mixed en/ru/ja/zh synthetic text per GPU, 120k-line vocab (SURVEY 8d config 3)"),
+    4: ("english", 1250.0, 29000, "configs[3]: %.0f MB English-shaped shard per GPU = one of the 8 shards of the 10 GB run (SURVEY 8d config 4)"),
+    5: ("deep", 1000.0, 0, "configs[4]: %.0f MB of 512-char words, every stem prefix a token (SURVEY 8d config 5)"),
+}
 
 
 def _cpu_baseline(text, vocab, target_bytes):
@@ -65,11 +79,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mb", type=float, default=100.0, help="shard size per GPU in MB (1 MB = 1e6 bytes)")
-    ap.add_argument("--vocab-size", type=int, default=29000)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="SURVEY 8d configuration (2 = the metric's)")
+    ap.add_argument("--mb", type=float, default=None, help="shard size per GPU in MB (1 MB = 1e6 bytes); default: the configuration's")
+    ap.add_argument("--vocab-size", type=int, default=None)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--cpu-sample-mb", type=float, default=32.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-to-host and fast-path measurements")
     ap.add_argument("--text-file", default=None, help="optional local corpus instead of the synthetic shard")
     ap.add_argument("--vocab-file", default=None)
     args = ap.parse_args()
@@ -79,6 +95,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+
+    # ---- workload: one shard per rank (generated before the GPU is touched: worker processes) ----
+    kind, mb_default, vs_default, wl_fmt = CONFIGS[args.config]
+    mb = args.mb if args.mb is not None else mb_default
+    vocab_size = args.vocab_size if args.vocab_size is not None else vs_default
+    nbytes_target = int(mb * 1e6)
+    if args.text_file and args.vocab_file:
+        with open(args.vocab_file, "rb") as f:
+            vocab = f.read().split(b"\n")
+            if vocab and vocab[-1] == b"":
+                vocab.pop()
+        with open(args.text_file, "rb") as f:
+            data = f.read()
+        s, e = W.shard_bounds(data, world)[rank]
+        text = data[s:e][:nbytes_target] if nbytes_target else data[s:e]
+        workload = "local files %s / %s" % (args.text_file, args.vocab_file)
+    else:
+        text, vocab = synth.parallel_corpus(kind, nbytes_target, args.seed, vocab_size, rank)
+        workload = (wl_fmt % mb) + ", %d-line %s vocab" % (len(vocab), "BERT-like" if kind != "deep" else "prefix")
+    nbytes = len(text)
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # WP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks
@@ -99,37 +136,17 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    # ---- workload: one shard per rank ----
-    nbytes_target = int(args.mb * 1e6)
-    if args.text_file and args.vocab_file:
-        with open(args.vocab_file, "rb") as f:
-            vocab = f.read().split(b"\n")
-            if vocab and vocab[-1] == b"":
-                vocab.pop()
-        with open(args.text_file, "rb") as f:
-            data = f.read()
-        s, e = W.shard_bounds(data, world)[rank]
-        text = data[s:e][:nbytes_target] if nbytes_target else data[s:e]
-        workload = "local files %s / %s" % (args.text_file, args.vocab_file)
-    else:
-        # one lexicon and one (replicated) vocabulary for all ranks; rank r > 0 draws its own word sequence
-        text, vocab = synth.english_corpus(nbytes_target, seed=args.seed, vocab_size=args.vocab_size,
-                                           text_seed=rank if rank > 0 else None)
-        workload = ("configs[1]: %.0f MB English-shaped synthetic shard per GPU (SURVEY 8d config 2), "
-                    "%d-line BERT-like vocab" % (args.mb, len(vocab)))
-    nbytes = len(text)
-
     vocab_h = W.Vocab(vocab, device=dev_index)
     vocab_h.set_option(W.WP_OPT_STAGE_TIMING, 1)
+    vocab_h.reserve(nbytes)
     pad = (-nbytes) % 16 + 16
     d_text = torch.zeros(nbytes + pad, dtype=torch.uint8, device=dev)
     d_text[:nbytes] = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
 
-    # The only collective: token ids -> rank 0 (all_gather of the counts, gather of fixed-capacity
-    # buffers).  Buffers are sized once, on the first (warm-up) step; after that the loop never reads a
-    # device value on the host, so the gather of step i runs on RCCL's stream while the kernels of
-    # step i+1 run on the encoder's streams.
+    # The only collective: token ids -> rank 0 (exact counts by all_gather, then one receive per peer into
+    # its place in a buffer sized once).  After the first step the loop never reads a device value on the
+    # host, so the gather of step i runs on RCCL's stream while the kernels of step i+1 run on the encoder's.
     gather = None
     if distributed:
         from wordpiece_amd.gather import IdGather
@@ -153,7 +170,7 @@ def main():
         step()
     fence()
     stage_ms = {}
-    radix_ms = radix_elems = radix_launches = 0
+    radix_ms = radix_elems = radix_launches = digit_bytes = 0
     t0 = time.perf_counter()
     n_ids = 0
     for _ in range(args.steps):
@@ -162,6 +179,7 @@ def main():
         radix_ms += st["ms_radix_scatter"]
         radix_elems += st["radix_pass_elems"]
         radix_launches += st["radix_passes"]
+        digit_bytes += st["radix_digit_bytes"]
         for k in ("ms_total", "ms_decode", "ms_sa", "ms_lcp", "ms_scan", "ms_walk"):
             stage_ms[k] = stage_ms.get(k, 0.0) + st[k]
     fence()
@@ -178,30 +196,39 @@ def main():
     else:
         dt_max, total_bytes = dt, float(nbytes)
 
+    ok = True
     if rank == 0:
+        steps = max(args.steps, 1)
         ms_per_step = dt_max / args.steps * 1e3
         value = total_bytes / 1e6 / (dt_max / args.steps)
-        # dominant kernel: the radix scatter pass; algorithmic bytes = 24 B per element moved
+        # dominant kernel: the radix scatter pass.  Algorithmic bytes per launch = 24 B per element moved (the
+        # 12-byte record read and written), - 4 B per symbol for the first pass, which makes the index column
+        # up instead of reading it, + 1 B per element for the digit byte it leaves for the next pass's histogram
         avg_launch_ms = radix_ms / max(radix_launches, 1)
-        # (the first pass of the round-0 sort makes the index column up instead of reading it: -4 B per symbol)
-        avg_launch_bytes = (RADIX_BYTES_PER_ELEM * radix_elems - 4 * st["n_total"] * args.steps) / max(radix_launches, 1)
+        avg_launch_bytes = (RADIX_BYTES_PER_ELEM * radix_elems - 4 * st["n_total"] * args.steps + digit_bytes) / max(radix_launches, 1)
         achieved = avg_launch_bytes / 1e9 / (avg_launch_ms / 1e3) if avg_launch_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "radix_scatter_traffic.json")
-        if os.path.exists(tfile) and abs(nbytes - 100_000_000) < 1_000_000:
+        if os.path.exists(tfile) and args.config == 2 and abs(nbytes - 100_000_000) < 1_000_000:
             # PMC bytes per launch, collected separately (rocprofv3 --pmc) on this very workload
             with open(tfile) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                tj = json.load(f)
+            if abs(tj.get("algorithmic_bytes_per_launch", 0) - avg_launch_bytes) < 0.02 * avg_launch_bytes:
+                traffic = tj.get("hbm_bytes_per_launch")
         out = {
-            "metric": "input MB/s tokenized (bert-base-cased vocab)", "value": round(value, 2), "unit": "MB/s",
+            "metric": "input MB/s tokenized (bert-base-cased vocab; offline stand-in: synthetic BERT-like vocab)",
+            "value": round(value, 2), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": workload, "bytes_per_gpu": nbytes, "vocab_lines": len(vocab),
-                       "symbols_n": st["n_total"], "ids_per_step_rank0": int(n_ids), "rounds": st["rounds"],
+            "config": {"workload": workload, "value_is": "device-resident: text already in HBM, ids left in HBM (host_to_host: the same through host buffers)",
+                       "bytes_per_gpu": nbytes, "vocab_lines": len(vocab),
+                       "symbols_n": st["n_total"], "n_text": st["n_text"], "vocab_in_s": st["vocab_in_s"],
+                       "ids_per_step_rank0": int(n_ids), "rounds": st["rounds"],
                        "sorted_depth": st["sorted_depth"], "symbol_bits": st["symbol_bits"],
                        "symbols_per_key": st["symbols_per_key"], "active_per_round": st["active_per_round"],
-                       "radix_launches_per_step": radix_launches // max(args.steps, 1),
-                       "id_gather": ("%s gather to rank 0" % ("rccl" if backend == "nccl" else backend)) if distributed
+                       "needed_after_round0": st["needed_after_round0"],
+                       "radix_launches_per_step": radix_launches // steps,
+                       "id_gather": ("%s: exact-size receives on rank 0" % ("rccl" if backend == "nccl" else backend)) if distributed
                        else "none (single GPU)"},
             "roofline": {"bound": "hbm", "kernel": "radix_scatter_kernel<uint64, 24> (full-size tiles; the round-0 suffix sort)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -209,27 +236,62 @@ def main():
                          "algorithmic_bytes_per_launch": int(avg_launch_bytes)},
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},
         }
-        # the whole SA/LCP stage against the HBM peak (DESIGN.md section 4 lists the per-kernel bytes):
-        # round-0 sort (32 B per element and pass: 8 histogram + 24 scatter, - 4 for the identity pass),
-        # round-0 split 35, rank store 32, rounds >= 1 per active entry: LDS sort 28 + split 50 + rank store 32
+        # the whole SA/LCP stage against the HBM peak, SURVEY 8(d) style: algorithmic bytes only (no histogram
+        # re-read of the keys: the histograms read the digit bytes)
         n_sym, act = st["n_total"], st["active_per_round"]
-        sa_bytes = 32 * (radix_elems / max(args.steps, 1)) - 4 * n_sym + (35 + 32) * n_sym + 110 * sum(act[1:])
-        sa_ms = stage_ms.get("ms_sa", 0.0) / max(args.steps, 1)
+        passes = radix_elems / steps
+        dig = (2 * digit_bytes / steps + n_sym) if digit_bytes else 8 * passes  # written + read (+ the key builder's bytes), or the 8-byte key read
+        sa_bytes = RADIX_BYTES_PER_ELEM * passes - 4 * n_sym + dig + (SPLIT_BYTES + RANK_STORE_BYTES) * n_sym + ROUND_BYTES * sum(act[1:])
+        sa_ms = stage_ms.get("ms_sa", 0.0) / steps
         if sa_ms > 0:
             out["sa_lcp_stage"] = {"algorithmic_bytes": int(sa_bytes), "ms": round(sa_ms, 3),
                                    "achieved": round(sa_bytes / 1e9 / (sa_ms / 1e3), 1), "unit": "GB/s",
-                                   "frac": round(sa_bytes / 1e9 / (sa_ms / 1e3) / HBM_PEAK_GBPS, 4)}
+                                   "frac": round(sa_bytes / 1e9 / (sa_ms / 1e3) / HBM_PEAK_GBPS, 4),
+                                   "per_symbol": {"radix_pass": RADIX_BYTES_PER_ELEM, "digit_bytes_total": round(dig / n_sym, 2),
+                                                  "split": SPLIT_BYTES, "rank_store": RANK_STORE_BYTES, "round_entry": ROUND_BYTES}}
+        if world == 1 and not args.no_extras:
+            # SURVEY 8(d)'s metric proper: host-resident text -> host-resident ids (pageable source, ids into a pinned
+            # block of the library's pool), wall clock around wp_linear_encode
+            vocab_h.encode(text[:1 << 20])
+            reps = max(2, min(args.steps, 5))
+            h2d = d2h = 0.0
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                ids_h = vocab_h.encode(text)
+                hs = vocab_h.stats()
+                h2d += hs["ms_h2d"]
+                d2h += hs["ms_d2h"]
+                del ids_h
+            hw = (time.perf_counter() - t1) / reps
+            out["host_to_host"] = {"ms_per_step": round(hw * 1e3, 3), "MB_per_s": round(nbytes / 1e6 / hw, 1),
+                                   "h2d_ms": round(h2d / reps, 3), "d2h_ms": round(d2h / reps, 3),
+                                   "note": "h2d_ms is host time of the (synchronous, pageable-source) upload; d2h into pinned memory"}
+            # the sibling fast path (word_piece::fast), device resident
+            vocab_h.fast_encode_device(d_text.data_ptr(), nbytes)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                f_ptr, f_n = vocab_h.fast_encode_device(d_text.data_ptr(), nbytes)
+            fw = (time.perf_counter() - t1) / reps
+            fast_ids = torch.as_tensor(_DevView(f_ptr, f_n), device=dev).clone() if f_n else None
+            l_ptr, l_n = vocab_h.encode_device(d_text.data_ptr(), nbytes)
+            same = bool(f_n == l_n and (f_n == 0 or torch.equal(fast_ids, torch.as_tensor(_DevView(l_ptr, l_n), device=dev))))
+            out["fast_path"] = {"ms_per_step": round(fw * 1e3, 3), "MB_per_s": round(nbytes / 1e6 / fw, 1),
+                                "ids_equal_linear_on_device": same}
         if world == 1 and not args.no_cpu_baseline:
             cb, cpu_ids = _cpu_baseline(text, vocab, int(args.cpu_sample_mb * 1e6))
             out["cpu_baseline"] = cb
             # the sample is a whitespace-cut prefix of the shard: its ids are a prefix of the GPU's
             d_ids, n = vocab_h.encode_device(d_text.data_ptr(), nbytes)
             gpu_ids = torch.as_tensor(_DevView(d_ids, n), device=dev)[:len(cpu_ids)].cpu().numpy()
-            out["config"]["ids_match_cpu_port_on_sample"] = bool(np.array_equal(gpu_ids, cpu_ids))
+            ok = bool(np.array_equal(gpu_ids, cpu_ids))
+            out["config"]["ids_match_cpu_port_on_sample"] = ok
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench.py: the HIP path's ids differ from the CPU port's on the sample")
 
 
 if __name__ == "__main__":

@@ -40,7 +40,7 @@ def _worker(rank, world, port, text, vocab, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 3])
 def test_sharded_gather_equals_unsharded(tmp_path, world):
     import oracle_lib as O
     from wordpiece_amd import synth

@@ -215,3 +215,30 @@ def test_symbol_limit_is_on_code_points():
     assert len(ids) == len(one) * reps
     assert np.array_equal(ids[:len(one)], one) and np.array_equal(ids[-len(one):], one)
     assert np.array_equal(ids.reshape(reps, len(one)), np.broadcast_to(one, (reps, len(one))))
+
+
+def test_id_gather_over_rccl_single_rank(corpus):
+    """The collective of bench.py (wordpiece_amd/gather.py) over backend nccl (= RCCL) with one rank on the
+    GPU: the RCCL calls of the multi-GPU path run here too (the world_size-2 form runs on gloo in
+    tests/test_distributed_gloo.py)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from wordpiece_amd.gather import IdGather
+    _, _, text, vocab, _ = corpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        gv = W.Vocab(vocab, device=0)
+        t = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+        g = IdGather(dist, 0, 1, dev)
+        for _ in range(2):
+            ids = gv.encode_tensor(t, copy=False)
+            g.step(ids, ids.numel(), before_collective=torch.cuda.current_stream().synchronize)
+        dist.barrier()
+        assert np.array_equal(g.result(), O.Vocab(vocab).encode(text))
+    finally:
+        dist.destroy_process_group()

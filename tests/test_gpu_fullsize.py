@@ -1,0 +1,107 @@
+"""GPU tests (-m gpu) at BASELINE.json's full single-GPU sizes: one 1.25 GB shard of config 4, config 3
+(1 GB mixed scripts) and config 5 (1 GB deep-prefix stress), plus the reference's 1e7-character
+single-word stress (tests/tests.cpp:266-272).  The oracle cannot run a gigabyte in seconds, so each
+config is checked through
+  * the shard property: ids(whole text) == concatenation of ids(~100 MB shards cut at
+    whitespace) — the 1 GB code path against the 100 MB code path,
+  * the CPU oracle on a whitespace-cut window at the start, one in the middle and one at the end of the
+    text, each located in the whole text's id stream by its offset,
+  * the sibling fast path on the device where the two algorithms must agree (configs 4 and 5)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import wordpiece_amd as W
+from wordpiece_amd import synth
+
+pytestmark = pytest.mark.gpu
+WS = (9, 10, 11, 12, 13, 32)
+
+
+def _cut(text, pos):
+    while pos < len(text) and text[pos] not in WS:
+        pos += 1
+    return pos
+
+
+def _oracle(vocab, chunk):
+    O.use_libsais(True)
+    try:
+        return O.Vocab(vocab).encode(chunk, threads=os.cpu_count() or 8)
+    finally:
+        O.use_libsais(False)
+
+
+def _check_config(kind, nbytes, vocab_size, window, expect_vocab_in_s=0, fast_must_agree=True):
+    text, vocab = synth.parallel_corpus(kind, nbytes, seed=100 if kind == "english" else 200 if kind == "multilingual" else 300,
+                                        vocab_size=vocab_size)
+    gv = W.Vocab(vocab)
+    gv.set_option(W.WP_OPT_STAGE_TIMING, 1)
+    gv.reserve(len(text))
+    ids = gv.encode(text)
+    st = gv.stats()
+    assert st["n_bytes"] == len(text) and st["n_ids"] == len(ids) and st["vocab_in_s"] == expect_vocab_in_s
+    # shard property: the big-input code path against the 100 MB code path
+    nshards = max(2, len(text) // 104_000_000)
+    bounds = W.shard_bounds(text, nshards)
+    counts = []
+    pos = 0
+    for a, b in bounds:
+        s_ids = gv.encode(text[a:b])
+        assert np.array_equal(s_ids, ids[pos:pos + len(s_ids)]), "shard [%d,%d)" % (a, b)
+        pos += len(s_ids)
+        counts.append(len(s_ids))
+    assert pos == len(ids)
+    # oracle windows: start, middle (inside a shard and across a shard cut), end
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    mid_shard = nshards // 2
+    windows = [(0, _cut(text, window)),
+               (bounds[mid_shard][0], _cut(text, bounds[mid_shard][0] + window)),
+               (_cut(text, len(text) - window), len(text))]
+    for wi, (a, b) in enumerate(windows):
+        exp = _oracle(vocab, text[a:b])
+        if wi == 2:
+            got = ids[len(ids) - len(exp):]
+        else:
+            start = int(offs[0 if wi == 0 else mid_shard])
+            got = ids[start:start + len(exp)]
+        assert np.array_equal(got, exp), "oracle window %d [%d,%d)" % (wi, a, b)
+    if fast_must_agree:
+        assert np.array_equal(gv.fast_encode(text), ids), "fast != linear on the device"
+    return st
+
+
+def test_config4_one_shard_1250mb():
+    st = _check_config("english", 1.25e9, 29000, 48_000_000)
+    assert st["rounds"] <= 4 and st["n_total"] == st["n_text"] + 1
+
+
+def test_config3_multilingual_1gb():
+    # (multi-char CJK tokens: Linear matches across CJK chars, Fast stops at them — no fast == linear here)
+    st = _check_config("multilingual", 1.0e9, 120000, 32_000_000, fast_must_agree=False)
+    assert st["alphabet"] > 255
+
+
+def test_config5_deep_prefix_1gb():
+    st = _check_config("deep", 1.0e9, 0, 32_000_000)
+    assert st["longest_token"] == 512 and st["rounds"] >= 7
+    assert 0 < st["needed_after_round0"] < st["n_total"] // 50
+
+
+@pytest.mark.parametrize("positive", [True, False])
+def test_reference_single_word_1e7(positive):
+    """tests.cpp:266-272: a 10,000,000-character word over a 30,000-entry split vocabulary; negative: the
+    smallest vocab line erased as in testRandomSplit (tests.cpp:238-240; the reference runs this size in
+    the positive form only)."""
+    s, vocab = synth.random_split_case(777, 10_000_000, 30_000, positive)
+    gv = W.Vocab(vocab)
+    ids = gv.encode(s)
+    assert np.array_equal(ids, gv.fast_encode(s))           # tests.cpp:90-97 on the device
+    assert np.array_equal(ids, O.Vocab(vocab).fast_encode(s))
+    assert np.array_equal(ids, _oracle(vocab, s))
+    # (greedy longest-match runs into a dead end on such a vocabulary — a short piece plus the head of the next
+    # one is itself a longer piece somewhere — so the word usually comes out as one -1; what is checked is
+    # that all four implementations agree)
+    assert len(ids) >= 1

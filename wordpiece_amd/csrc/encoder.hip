@@ -797,7 +797,8 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       // S = text . 1: the reach of every token is its range in the sorted keys (prune.h); long tokens are
       // narrowed inside their refined group.  The marks arrive sorted (tokens in lexicographic order).
       if (M > 0) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(long_token_range_kernel<SymT>), dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, d_sa,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(long_token_range_kernel<SymT>), dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)),
+                           dim3(kBlock), 0, st, d_sa,
                            d_sym, n, c->d_stream, c->d_elig_start, c->d_elig_info, M, c->d_lut, d_rng_lo, d_rng_hi,
                            d_rng_long);
         hipLaunchKernelGGL(virtual_marks_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, d_rng_lo, d_rng_hi, M,

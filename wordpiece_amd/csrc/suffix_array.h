@@ -93,7 +93,14 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
     bool f = false, sg = true, act = false;
     if (k < m) {
       rr_flags(keys, m, k, f, sg);
-      if (!sg) {
+      if (ROUND0 && rule.need_map) {
+        // pruned round 0: only the entries of needed groups can stay, only they need a depth here (the
+        // apply pass computes the depths it stores itself); nothing goes through tdep
+        if (!sg && rule.need_map[k]) {
+          const uint32_t nd = static_cast<uint32_t>(count_key_symbols(keys[k], kKeyBits, s_fl, uniform_bits));
+          act = nd < rule.need;
+        }
+      } else if (!sg) {
         uint32_t nd;
         if (ROUND0) {
           nd = static_cast<uint32_t>(count_key_symbols(keys[k], kKeyBits, s_fl, uniform_bits));
@@ -313,7 +320,13 @@ __device__ __forceinline__ void rr_first_half(RrTile &T, const uint64_t *__restr
       const uint64_t next = k + 1 < m ? keys[k + 1] : ~me;
       f = prev != me;
       sg = f && next != me;
-      if (!sg) {
+      if (ROUND0 && rule.need_map) {
+        // pruned round 0: a depth is needed for the entries that may stay and for the heads of tied groups
+        // (kept at gdepth[] for the rounds that double through them); computed here, no tdep round trip
+        const bool needed = !sg && rule.need_map[k];
+        if (needed || (f && !sg)) nd = static_cast<uint32_t>(count_key_symbols(me, kKeyBits, s_fl, uniform_bits));
+        act = needed && nd < rule.need;
+      } else if (!sg) {
         if (!OWN_DEPTH) {
           nd = tdep[k];
         } else if (ROUND0) {

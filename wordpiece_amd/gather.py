@@ -1,9 +1,12 @@
 """Token-id gather of the multi-GPU path: the only collective.
 
-Every rank tokenizes its own shard; the id streams are collected on rank 0 in shard order.
-`IdGather` sizes fixed-capacity buffers on the first step and afterwards never reads a device value
-on the host, so over RCCL the gather of step i overlaps the kernels of step i+1.
+Every rank tokenizes its own shard; the id streams are collected on rank 0 in shard order with exact
+sizes: an all_gather of the counts, then one point-to-point receive per peer straight into its place
+in rank 0's buffer (RCCL send/recv over the peer's own xGMI link; no max-padded gather, so rank 0
+holds sum(counts) ids and nothing else).  The buffer grows on demand and is reused across steps.
 Used by bench.py (backend nccl = RCCL, or gloo for rehearsals) and tests/test_distributed_gloo.py.
+(The single-process form of the same thing is wp_linear_encode_multi behind the C ABI: one host thread
+and context per GPU, ids downloaded into one host buffer.)
 """
 import torch
 
@@ -11,36 +14,52 @@ import torch
 class IdGather:
     def __init__(self, dist, rank, world, device):
         self.dist, self.rank, self.world, self.device = dist, rank, world, device
-        self.cap = None
+        self.cnt = torch.zeros(1, dtype=torch.int64, device=device)
+        self.counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        self.buf = None     # rank 0: all ids in shard order
+        self.send = None    # other ranks: staging copy of the own ids (the encoder reuses its buffer)
+        self.host_counts = [0] * world
 
-    def _size(self, n_ids):
-        cnt = torch.tensor([n_ids], dtype=torch.int64, device=self.device)
-        counts = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
-        self.dist.all_gather(counts, cnt)
-        self.cap = int(int(torch.stack(counts).max().item()) * 1.1) + 1024
-        self.cnt, self.counts = cnt, counts
-        self.send = torch.zeros(self.cap, dtype=torch.int32, device=self.device)
-        self.recv = ([torch.empty(self.cap, dtype=torch.int32, device=self.device) for _ in range(self.world)]
-                     if self.rank == 0 else None)
+    def _room(self, t, n):
+        if t is None or t.numel() < n:
+            t = torch.empty(int(n * 1.05) + 1024, dtype=torch.int32, device=self.device)
+        return t
 
     def step(self, ids, n_ids, before_collective=None):
         """ids: int32 tensor (any device) holding n_ids ids.  before_collective(): called after the ids
         have been copied out of `ids` (bench.py synchronises there, because the encoder reuses the buffer)."""
-        if self.cap is None:
-            self._size(n_ids)
-        if n_ids > self.cap:
-            raise RuntimeError("id count %d exceeds the gather capacity %d" % (n_ids, self.cap))
+        dist = self.dist
         self.cnt.fill_(n_ids)
-        if n_ids:
-            self.send[:n_ids].copy_(ids[:n_ids] if ids.device == self.send.device else ids[:n_ids].to(self.send.device))
+        dist.all_gather(self.counts, self.cnt)
+        self.host_counts = [int(c.item()) for c in self.counts]
+        if self.rank == 0:
+            total = sum(self.host_counts)
+            self.buf = self._room(self.buf, total)
+            if n_ids:
+                self.buf[:n_ids].copy_(ids[:n_ids])
+        else:
+            self.send = self._room(self.send, n_ids)
+            if n_ids:
+                self.send[:n_ids].copy_(ids[:n_ids])
         if before_collective:
             before_collective()
-        self.dist.all_gather(self.counts, self.cnt)
-        self.dist.gather(self.send, self.recv, dst=0)
+        if self.world == 1:
+            return
+        ops = []
+        if self.rank == 0:
+            off = self.host_counts[0]
+            for r in range(1, self.world):
+                if self.host_counts[r]:
+                    ops.append(dist.P2POp(dist.irecv, self.buf[off:off + self.host_counts[r]], r))
+                off += self.host_counts[r]
+        elif n_ids:
+            ops.append(dist.P2POp(dist.isend, self.send[:n_ids], 0))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
 
     def result(self):
         """rank 0: the ids of all shards in shard order (numpy int32); other ranks: None."""
         if self.rank != 0:
             return None
-        import numpy as np
-        return np.concatenate([self.recv[r][:int(self.counts[r].item())].cpu().numpy() for r in range(self.world)])
+        return self.buf[:sum(self.host_counts)].cpu().numpy()

@@ -219,3 +219,75 @@ def random_split_case(seed, text_len, parts, positive=True):
     if not positive:
         vocab = vocab[1:]
     return s.encode(), vocab
+
+
+# ---- large shards: ~100 MB chunks from worker processes -------------------------------------------------
+def _gen_chunk(args):
+    kind, nbytes, seed, k, vocab_size = args
+    if kind == "english":
+        text, vocab = english_corpus(nbytes, seed=seed, vocab_size=vocab_size, text_seed=(1000 * seed + k) if k else None)
+    elif kind == "multilingual":
+        text, vocab = multilingual_corpus(nbytes, seed=seed + 7 * k, vocab_size=vocab_size)
+    else:
+        text, vocab = deep_prefix_corpus(nbytes, seed=seed, words_seed=k if k else None)
+    if not text.endswith((b" ", b"\n")):
+        text += b"\n"
+    return text, (vocab if k == 0 else None)
+
+
+def parallel_corpus(kind, nbytes, seed=2, vocab_size=29000, rank=0, workers=None):
+    """A shard of ~nbytes: chunks of ~100 MB generated by worker processes (plain `python -c` children
+    that import this module only: they never touch the GPU and do not depend on how the parent was
+    started), the vocabulary from chunk 0 of rank 0 (english / deep: one lexicon and vocabulary for
+    every chunk and rank, a different word sequence per chunk; multilingual: chunk 0's vocabulary).
+    kind: "english" | "multilingual" | "deep".  Returns (bytes, vocab)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    nbytes = int(nbytes)
+    nchunks = max(1, int(round(nbytes / 100e6)))
+    if nchunks == 1:
+        if kind == "english":
+            return english_corpus(nbytes, seed=seed, vocab_size=vocab_size, text_seed=rank if rank > 0 else None)
+        return _gen_chunk((kind, nbytes, seed, 0, vocab_size))
+    jobs = [(kind, nbytes // nchunks, seed, (64 * rank + k) if (rank or k) else 0, vocab_size) for k in range(nchunks)]
+    if rank > 0:  # chunk 0 of rank 0 defines the vocabulary: regenerate it for the other ranks
+        jobs.insert(0, (kind, 4_000_000 if kind != "multilingual" else nbytes // nchunks, seed, 0, vocab_size))
+    workers = workers or min(len(jobs), max(2, (os.cpu_count() or 8) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))), 16)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json; sys.path.insert(0, %r); from wordpiece_amd import synth; a = json.loads(sys.argv[1]); "
+            "t, v = synth._gen_chunk(tuple(a)); open(sys.argv[2], 'wb').write(t); "
+            "json.dump([w if isinstance(w, str) else w.decode('utf8') for w in v], open(sys.argv[2] + '.vocab', 'w')) if v is not None else None" % root)
+    parts = [None] * len(jobs)
+    with tempfile.TemporaryDirectory(prefix="wp_corpus_") as tmp:
+        running = {}
+        nxt = 0
+        while nxt < len(jobs) or running:
+            while nxt < len(jobs) and len(running) < workers:
+                path = os.path.join(tmp, "chunk%d.bin" % nxt)
+                running[nxt] = (subprocess.Popen([sys.executable, "-c", code, json.dumps(list(jobs[nxt])), path]), path)
+                nxt += 1
+            done = [k for k, (pr, _) in running.items() if pr.poll() is not None]
+            if not done:
+                next(iter(running.values()))[0].wait(timeout=600)
+                continue
+            for k in done:
+                pr, path = running.pop(k)
+                if pr.returncode != 0:
+                    for other, _ in running.values():
+                        other.kill()
+                    raise RuntimeError("corpus worker %d failed (exit %d)" % (k, pr.returncode))
+                with open(path, "rb") as f:
+                    text = f.read()
+                vocab = None
+                if os.path.exists(path + ".vocab"):
+                    with open(path + ".vocab") as f:
+                        vocab = json.load(f)
+                os.remove(path)
+                parts[k] = (text, vocab)
+    vocab = parts[0][1]
+    if rank > 0:
+        parts = parts[1:]
+    return b"".join(p[0] for p in parts), vocab
