@@ -412,7 +412,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   static const bool env_no_digit_bytes = env_flag("WP_NO_DIGIT_BYTES");
   const bool use_digit_bytes = !env_no_digit_bytes && kRadixBits <= 8 && n > kRadixSmallN;
   SymT *d_sym = nullptr;
-  uint8_t *DG0 = nullptr, *DG1 = nullptr, *d_need = nullptr, *d_rng_long = nullptr;
+  uint8_t *DG0 = nullptr, *DG1 = nullptr, *d_rng_long = nullptr;
   uint32_t *d_rng_lo = nullptr, *d_rng_hi = nullptr;
   uint32_t *d_claim = nullptr;
   size_t claim_size = 1024;  // hash table of claimed key ranges (prune.h): a power of two >= 2 M
@@ -443,7 +443,6 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     K1 = ar.take<uint64_t>(n);
     DG0 = use_digit_bytes ? ar.take<uint8_t>(n + 64) : nullptr;
     DG1 = use_digit_bytes ? ar.take<uint8_t>(n + 64) : nullptr;
-    d_need = ar.take<uint8_t>(n + 64);
     d_claim = ar.take<uint32_t>(claim_size);
     V0 = ar.take<uint32_t>(n);
     V1 = ar.take<uint32_t>(n);
@@ -614,19 +613,6 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
                                        code.uniform_bits ? 0 : hist_atomic_bits, db);
   uint64_t *keys = cur ? K1 : K0;
   uint32_t *vals = cur ? V1 : V0, *other_vals = cur ? V0 : V1;
-  if (prune) {
-    WP_HIP(hipMemsetAsync(d_need, 0, n, st));
-    WP_HIP(hipMemsetAsync(d_claim, 0xff, claim_size * sizeof(uint32_t), st));
-    if (M > 0) {  // (no eligible token at all: every tied group retires)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(need_groups_kernel<SymT>), dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)),
-                         dim3(kBlock), 0, st, keys, vals, n, d_sym, c->d_stream, c->d_elig_start, c->d_elig_info, M,
-                         c->d_lut, dcode, d_claim, static_cast<uint32_t>(claim_size - 1), d_need,
-                         reinterpret_cast<unsigned long long *>(c->d_scalars + 18), text_only ? d_rng_lo : nullptr,
-                         d_rng_hi, d_rng_long);
-    }
-    rule.need_map = d_need;
-    rule.sa_needed_only = (text_only && !v->keep_debug) ? 1 : 0;
-  }
   uint32_t *slots = AS0, *other_slots = AS1;
   uint32_t *adep = AD0, *other_dep = AD1;
   bool classified = false;
@@ -643,7 +629,27 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     lb.ticket = reinterpret_cast<uint32_t *>(lb.wb + tiles);
     const size_t lb_bytes = static_cast<size_t>(tiles) * 16 + 16;
     RankEntry *hd = reinterpret_cast<RankEntry *>(cur ? K0 : K1);
-    if (fused_rerank) {
+    if (prune) {
+      // Depth-capped mode: the groups that have to go on are found from the vocabulary (prune.h) and appended
+      // to the active list by the kernel that finds them — on the side stream (a few thousand waves of
+      // binary searches), next to the streaming kernel that turns the sorted keys into ranks and LCPs.
+      fork();
+      WP_HIP(hipMemsetAsync(d_claim, 0xff, claim_size * sizeof(uint32_t), st2));
+      NeededList nl{slots, other_vals, AG, adep, d_ghead, d_large_id, d_large_off,  // (the large-group tables are free until the classification)
+                    reinterpret_cast<unsigned long long *>(c->d_scalars + 4),
+                    text_only && !v->keep_debug ? d_sa : nullptr, need_depth};
+      if (M > 0) {  // (no eligible token at all: every tied group retires)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(need_groups_kernel<SymT>), dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)),
+                           dim3(kBlock), 0, st2, keys, vals, n, d_sym, c->d_stream, c->d_elig_start, c->d_elig_info, M,
+                           c->d_lut, dcode, d_claim, static_cast<uint32_t>(claim_size - 1), nl,
+                           text_only ? d_rng_lo : nullptr, d_rng_hi, d_rng_long);
+      }
+      hipLaunchKernelGGL(needed_list_close_kernel, dim3(1), dim3(1), 0, st2, c->d_scalars + 4, d_ghead);
+      if (M > 0) hipLaunchKernelGGL(needed_fill_kernel, dim3(1024), dim3(kBlock), 0, st2, nl, vals);
+      hipLaunchKernelGGL(round0_rank_kernel, dim3(cdiv(n, kR0Tile)), dim3(kBlock), 0, st, keys, vals, n, dcode.first_len,
+                         dcode.uniform_bits, (v->keep_debug || v->lcp_kasai) ? d_sa : nullptr, hd, d_lcp, d_gdepth);
+      join();  // the rank store below reuses the key buffer as scratch: the searches in it must be over
+    } else if (fused_rerank) {
       WP_HIP(hipMemsetAsync(lb.wa, 0, lb_bytes, st));
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_fused_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
                          vals, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), n, tiles,
@@ -707,6 +713,14 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   int rounds = 1;
   S.active_per_round[0] = static_cast<int64_t>(n);
   while (n_act > 0) {
+    // A round adds to a group's depth the depth of the group its second keys point into: that doubles the
+    // depth while those groups are refined too (full depth: 31 rounds for 2^31 symbols), and adds at least the
+    // depth of a round-0 group — one symbol or more — when they retired in round 0 (depth-capped mode: a
+    // vocabulary of 512-symbol tokens takes ~60 rounds over its short list).  More rounds than that can only
+    // mean corrupted ranks: stop instead of spinning.
+    if (static_cast<uint64_t>(rounds) > 80 + (full ? 0ull : static_cast<uint64_t>(need_depth))) {
+      throw HipError("prefix doubling did not converge (internal error)");
+    }
     if (rounds < 40) S.active_per_round[rounds] = static_cast<int64_t>(n_act);
     // small groups: one LDS-resident segmented sort per window of the list (already queued by
     // next_round_begin: avals -> (K0, spare_vals))
@@ -961,11 +975,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   }
   fetch_scalars(c, 20);
   n_ids = n_text > 0 ? c->h_scalars[9] : 0;
-  {
-    unsigned long long needed = 0;
-    std::memcpy(&needed, c->h_scalars + 18, sizeof(needed));
-    S.needed_after_round0 = prune ? static_cast<int64_t>(needed) : -1;
-  }
+  S.needed_after_round0 = prune ? (rounds > 1 ? S.active_per_round[1] : 0) : -1;
 
   S.n_ids = static_cast<int64_t>(n_ids);
   S.radix_passes = c->rstats.passes;

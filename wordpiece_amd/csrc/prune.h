@@ -13,7 +13,9 @@
 // (config 5) only the word starts (1/512 of the positions) stay instead of everything.
 //
 // need_groups_kernel: one wave per eligible token: key of the token, equal range in the sorted keys
-// (binary search), first claimant of a range fills need[lo..hi) with 1.
+// (binary search); the first claimant of a range appends the group to the active list of round 1
+// (list space and group number from one 64-bit atomic, so that both grow together) — round 0 needs no
+// counting and compaction passes for it.
 #pragma once
 #include "decode.h"
 #include "primitives.h"
@@ -89,6 +91,15 @@ __device__ __forceinline__ int suffix_vs_token(const SymT *__restrict__ sym, siz
 // (nullptr: not wanted) receive it for tokens whose stream fits the key; for long tokens they receive
 // the group that carries the token's key (refined by the rounds, then narrowed by
 // long_token_range_kernel) and rng_long[m] = 1.
+// next active list (suffix_array.h): slots, suffixes, group numbers, depths, group table
+struct NeededList {
+  uint32_t *slots, *vals, *gid, *dep, *ghead;
+  uint32_t *gfirst, *gdepth;   // per group: its first slot and its depth (the entries are written by needed_fill_kernel)
+  unsigned long long *totals;  // low word: list entries, high word: groups (one atomic allocates both)
+  uint32_t *sa;                // != nullptr: slot -> suffix for the slots of needed groups (text-only layout)
+  uint32_t need_depth;         // a group whose depth reaches this needs no refinement (depth cap)
+};
+
 template <typename SymT>
 __global__ __launch_bounds__(kBlock) void need_groups_kernel(const uint64_t *__restrict__ keys,
                                                              const uint32_t *__restrict__ vals, size_t n,
@@ -98,9 +109,8 @@ __global__ __launch_bounds__(kBlock) void need_groups_kernel(const uint64_t *__r
                                                              const uint32_t *__restrict__ tok_info, int M,
                                                              const uint32_t *__restrict__ lut_excl, DevCode code,
                                                              uint32_t *__restrict__ claim, uint32_t claim_mask,
-                                                             uint8_t *__restrict__ need,
-                                                             unsigned long long *__restrict__ n_needed,
-                                                             uint32_t *__restrict__ rng_lo, uint32_t *__restrict__ rng_hi,
+                                                             NeededList out, uint32_t *__restrict__ rng_lo,
+                                                             uint32_t *__restrict__ rng_hi,
                                                              uint8_t *__restrict__ rng_long) {
   const int m = static_cast<int>((static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6);
   const int lane = lane_id();
@@ -145,24 +155,61 @@ __global__ __launch_bounds__(kBlock) void need_groups_kernel(const uint64_t *__r
     rng_hi[m] = static_cast<uint32_t>(last);
     rng_long[m] = 1;
   }
-  // several tokens share a key (all long prefixes of one word): the first to claim the range fills it
-  int won = 0;
+  // several tokens share a key (all long prefixes of one word): the first to claim the range appends it
+  unsigned long long got = ~0ull;
+  uint32_t depth = 0;
   if (lane == 0) {
     uint32_t h = (static_cast<uint32_t>(first) * 2654435761u) & claim_mask;
+    bool won = false;
     for (;;) {
       const uint32_t old = atomicCAS(&claim[h], kClaimEmpty, static_cast<uint32_t>(first));
       if (old == kClaimEmpty) {
-        won = 1;
+        won = true;
         break;
       }
       if (old == static_cast<uint32_t>(first)) break;
       h = (h + 1) & claim_mask;
     }
-    if (won && n_needed) atomicAdd(n_needed, static_cast<unsigned long long>(last - first));
+    if (won) {
+      depth = static_cast<uint32_t>(count_key_symbols(key, kKeyBits, code.first_len, code.uniform_bits));
+      if (depth < out.need_depth) {
+        got = atomicAdd(out.totals, (1ull << 32) | static_cast<unsigned long long>(last - first));
+      }
+    }
   }
-  won = __shfl(won, 0, kWave);
-  if (!won) return;
-  for (size_t k = first + lane; k < last; k += kWave) need[k] = 1;
+  if (lane == 0 && got != ~0ull) {  // the entries themselves: needed_fill_kernel, one thread per entry
+    const uint32_t g = static_cast<uint32_t>(got >> 32);
+    out.ghead[g] = static_cast<uint32_t>(got);
+    out.gfirst[g] = static_cast<uint32_t>(first);
+    out.gdepth[g] = depth;
+  }
+}
+
+// entries of the needed groups: list position p belongs to the group g with ghead[g] <= p < ghead[g+1]
+// (ghead ascends with g: both come from one atomic) and is slot gfirst[g] + p - ghead[g]
+__global__ __launch_bounds__(kBlock) void needed_fill_kernel(NeededList out, const uint32_t *__restrict__ sorted_vals) {
+  const uint32_t *t32 = reinterpret_cast<const uint32_t *>(out.totals);
+  const uint32_t n_act = t32[0], n_groups = t32[1];
+  for (size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; p < n_act;
+       p += static_cast<size_t>(gridDim.x) * kBlock) {
+    uint32_t lo = 0, hi = n_groups;  // last group with ghead[g] <= p
+    while (hi - lo > 1) {
+      const uint32_t md = (lo + hi) >> 1;
+      if (out.ghead[md] <= p) lo = md; else hi = md;
+    }
+    const uint32_t k = out.gfirst[lo] + static_cast<uint32_t>(p - out.ghead[lo]);
+    const uint32_t v = sorted_vals[k];
+    out.slots[p] = k;
+    out.vals[p] = v;
+    out.gid[p] = lo;
+    out.dep[p] = out.gdepth[lo];
+    if (out.sa) out.sa[k] = v;
+  }
+}
+
+// group g of the list is [ghead[g], ghead[g+1]): the closing entry
+__global__ void needed_list_close_kernel(const uint32_t *__restrict__ totals, uint32_t *__restrict__ ghead) {
+  ghead[totals[1]] = totals[0];
 }
 
 // wave-wide form of suffix_vs_token: lane j compares symbol j (64 symbols per step)

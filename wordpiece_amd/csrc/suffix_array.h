@@ -492,6 +492,95 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
                                hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, nullptr, rule);
 }
 
+// ---- round 0 in the depth-capped mode: ranks and LCPs only ---------------------------------------------
+// With the pruning of prune.h the next active list is written by the kernel that finds the needed
+// groups, so round 0 needs no counting pass, no tile prefix and no compaction: one streaming kernel turns
+// the sorted keys into rank entries (the first slot of every suffix's group), the LCP of every boundary
+// (complete codewords inside the common bits of two neighbouring keys; -1 = "same key") and the depth
+// of every tied group (kept at gdepth[first slot] for the rounds that double through it).
+// The one dependency across tiles — where does the group that reaches into this wave's first entry
+// start — is answered by the keys themselves: a look at the 64 entries in front of the wave, and a
+// binary search in the sorted keys for the rare group that is longer than that.
+constexpr int kR0Rounds = 16;  // 1024 entries per wave: the look behind the wave is paid once per 1024 entries
+constexpr int kR0Tile = kBlock * kR0Rounds;
+__global__ __launch_bounds__(kBlock) void round0_rank_kernel(const uint64_t *__restrict__ keys,
+                                                             const uint32_t *__restrict__ vals, size_t n,
+                                                             const uint8_t *__restrict__ first_len, int uniform_bits,
+                                                             uint32_t *__restrict__ sa_dbg, RankEntry *__restrict__ hd,
+                                                             int32_t *__restrict__ lcp, uint32_t *__restrict__ gdepth) {
+  __shared__ uint8_t s_fl[kDecodeTableBytes];
+  const int lane = lane_id(), w = wave_id();
+  const size_t wave_base = static_cast<size_t>(blockIdx.x) * kR0Tile + static_cast<size_t>(w) * (kWave * kR0Rounds);
+  // all loads of the wave are issued before anything waits: a lane's key in every round (the neighbours'
+  // keys come by lane shuffles, the two at the round edges from the 65th / 0th load), and the 64 keys in
+  // front of the wave for the carried head
+  uint64_t me[kR0Rounds];
+#pragma unroll
+  for (int r = 0; r < kR0Rounds; r++) {
+    const size_t k = wave_base + static_cast<size_t>(r) * kWave + lane;
+    me[r] = k < n ? keys[k] : ~0ull;
+  }
+  const bool have_front = wave_base < n && wave_base >= 1 + static_cast<size_t>(lane);
+  const uint64_t front = have_front ? keys[wave_base - 1 - lane] : ~0ull;  // lane l: the key l + 1 entries in front
+  const size_t after_idx = wave_base + static_cast<size_t>(kWave) * kR0Rounds;
+  const uint64_t after = after_idx < n ? keys[after_idx] : ~0ull;  // (wave-uniform address: one broadcast load)
+  if (uniform_bits <= 0) {
+    for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
+      reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
+    }
+  }
+  __syncthreads();
+  if (wave_base >= n) return;
+  size_t carry = wave_base;  // head of the group of the entries in front of the first head seen by this wave
+  {
+    const uint64_t me0 = __shfl(me[0], 0, kWave);
+    const uint64_t neq = ~__ballot(have_front && front == me0);
+    if (neq & 1ull) {
+      carry = wave_base;  // the entry in front has another key (or there is none): the wave starts a group
+    } else if (neq) {
+      carry = wave_base - static_cast<size_t>(__ffsll(static_cast<long long>(neq)) - 1);
+    } else {  // a group of more than 64 entries reaches in: its first entry by binary search
+      size_t lo = 0, hi = wave_base - kWave;
+      while (lo < hi) {
+        const size_t md = (lo + hi) >> 1;
+        if (keys[md] < me0) lo = md + 1; else hi = md;
+      }
+      carry = lo;
+    }
+  }
+  uint64_t prev_last = __shfl(front, 0, kWave);  // key of the entry in front of the current round
+#pragma unroll
+  for (int r = 0; r < kR0Rounds; r++) {
+    const size_t round_base = wave_base + static_cast<size_t>(r) * kWave;
+    const size_t k = round_base + lane;
+    const bool valid = k < n;
+    const uint64_t up = __shfl_up(me[r], 1, kWave), dn = __shfl_down(me[r], 1, kWave);
+    const uint64_t next_first = r + 1 < kR0Rounds ? __shfl(me[r + 1 < kR0Rounds ? r + 1 : r], 0, kWave) : after;
+    const uint64_t prev = lane == 0 ? prev_last : up;
+    const uint64_t next = lane == kWave - 1 ? next_first : dn;
+    // (k == 0: prev_last is ~0, never a key; past the end: ~0 as well, so the last entry sees another key)
+    const bool f = valid && prev != me[r];
+    const bool sg = f && next != me[r];
+    const uint64_t bf = __ballot(f);
+    if (valid) {
+      const uint64_t mine = bf & (((1ull << lane) - 1ull) | (1ull << lane));
+      const size_t head = mine ? round_base + static_cast<size_t>(63 - __clzll(static_cast<long long>(mine))) : carry;
+      hd[k] = static_cast<RankEntry>(head);
+      if (sa_dbg) sa_dbg[k] = vals[k];
+      if (k > 0) {
+        int32_t l = -1;
+        if (f) {
+          l = count_key_symbols(me[r], __clzll(static_cast<long long>(me[r] ^ prev)) - (64 - kKeyBits), s_fl, uniform_bits);
+        }
+        lcp[k - 1] = l;
+      }
+      if (f && !sg) gdepth[k] = static_cast<uint32_t>(count_key_symbols(me[r], kKeyBits, s_fl, uniform_bits));
+    }
+    if (bf) carry = round_base + static_cast<size_t>(63 - __clzll(static_cast<long long>(bf)));
+    prev_last = __shfl(me[r], kWave - 1, kWave);
+  }
+}
+
 // ---- single-pass form: the two passes fused with a chained scan ----------------------------------
 // The split of a round needs, per tile of the list, the exclusive prefix of three scalars (entries
 // that stay active, their group heads, position of the last group head).  Here every workgroup takes
