@@ -34,7 +34,7 @@ from wordpiece_amd import synth  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
 RADIX_BYTES_PER_ELEM = 24  # one radix pass reads and writes a 12-byte (key, index) record
 # SA/LCP stage, algorithmic bytes per symbol besides the radix passes:
-SPLIT_BYTES = 30       # round-0 split: keys 8 + need map 1 (count pass); keys 8 + index 4 + need map 1 read, rank 4 + LCP 4 written
+SPLIT_BYTES = 16       # round 0 after the sort (round0_rank_kernel): keys 8 read, rank 4 + LCP 4 written
 RANK_STORE_BYTES = 32  # destination partition (4 read; 8 read + 8 written) + scatter (8 read, 4 written)
 ROUND_BYTES = 110      # rounds >= 1, per list entry: LDS sort 28 + split 50 + rank store 32
 

@@ -242,3 +242,41 @@ def test_id_gather_over_rccl_single_rank(corpus):
         assert np.array_equal(g.result(), O.Vocab(vocab).encode(text))
     finally:
         dist.destroy_process_group()
+
+
+def test_debug_bounds_build_is_clean(tmp_path):
+    """libwordpiece_amd_dbg.so (-DWP_DEBUG_BOUNDS): every store / gather whose address comes out of a computed
+    table — radix scatter offsets, rank destinations, token ids from the step table, slots of the needed
+    list — is range-checked; a violation would make the encode fail with the per-site counts instead of
+    faulting.  Run in a child process (the library path is fixed at import time)."""
+    dbg = os.path.join(PKG, "libwordpiece_amd_dbg.so")
+    assert os.path.exists(dbg), "run `python -m wordpiece_amd.build`"
+    script = tmp_path / "dbg_run.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+import numpy as np
+import oracle_lib as O, wordpiece_amd as W
+from wordpiece_amd import synth
+cases = [synth.english_corpus(6_000_000, seed=61, vocab_size=6000),
+         synth.multilingual_corpus(3_000_000, seed=62, vocab_size=8000),
+         synth.deep_prefix_corpus(3_000_000, seed=63),
+         (b"ab " * 7 + b"x" * 200_000 + b" ab", ["a", "##b", "x", "##x", "ab"]),
+         (b"ab", ["a", "##b"])]
+for text, vocab in cases:
+    for opts in ({}, {W.WP_OPT_VOCAB_IN_S: 1}, {W.WP_OPT_FULL_DEPTH: 1}):
+        if opts.get(W.WP_OPT_FULL_DEPTH) and len(text) > 4_000_000:
+            continue
+        gv = W.Vocab(vocab)
+        for k, val in opts.items():
+            gv.set_option(k, val)
+        ids = gv.encode(text)
+        assert gv.stats()["reserved0"] == 1, "not the bounds-checking build"
+        assert np.array_equal(ids, O.Vocab(vocab).encode(text, threads=8))
+        assert np.array_equal(gv.fast_encode(text), O.Vocab(vocab).fast_encode(text, threads=8))
+print("DEBUG_BOUNDS_OK")
+''' % (os.path.dirname(PKG), os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, WP_LIB=dbg)
+    r = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "DEBUG_BOUNDS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -8,6 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwordpiece_amd.so")
+LIB_DBG = os.path.join(HERE, "libwordpiece_amd_dbg.so")  # -DWP_DEBUG_BOUNDS (csrc/common.h): checked scatters
 RUNNER = os.path.join(HERE, "runner")
 CPPTEST = os.path.join(HERE, "test_word_piece")
 SOURCES = ["encoder.hip", "word_piece.cpp"]
@@ -30,13 +31,19 @@ def _deps():
     return out
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, debug=True):
     hipcc = os.environ.get("HIPCC", "hipcc")
     deps = _deps()
     if force or _newer(LIB, deps):
         cmd = [hipcc, "-O3", "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-shared", "-Wall",
                "-Wno-unused-function"] + os.environ.get("WP_HIPCC_FLAGS", "").split() + [
                "-x", "hip", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    if debug and (force or _newer(LIB_DBG, deps)):
+        cmd = [hipcc, "-O3", "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+               "-DWP_DEBUG_BOUNDS", "-x", "hip", "-o", LIB_DBG] + [os.path.join(CSRC, s) for s in SOURCES]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

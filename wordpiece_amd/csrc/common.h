@@ -29,6 +29,21 @@ struct HipError : std::runtime_error {
 
 inline unsigned cdiv(size_t a, size_t b) { return static_cast<unsigned>((a + b - 1) / b); }
 
+// Debug build (-DWP_DEBUG_BOUNDS, libwordpiece_amd_dbg.so): the stores / gathers whose address comes out of
+// a computed table (radix offsets, rank destinations, token ids, list slots) check it first; a violation is
+// counted per site and skipped instead of faulting the GPU, and the encode fails with the counts.
+// Release build: the checks compile to nothing.
+enum BoundSite { kSiteRadixScatter = 0, kSiteRankStore = 1, kSiteTokenId = 2, kSiteListSlot = 3, kBoundSites = 4 };
+#ifdef WP_DEBUG_BOUNDS
+__device__ unsigned int g_wp_oob[kBoundSites];
+__device__ __forceinline__ bool wp_in_bounds(bool ok, int site) {
+  if (!ok) atomicAdd(&g_wp_oob[site], 1u);
+  return ok;
+}
+#else
+__device__ __forceinline__ bool wp_in_bounds(bool, int) { return true; }
+#endif
+
 // ---- character classes: utf8.cpp:10-29 of the reference --------------------------------
 constexpr uint32_t kSpaceToken = 9601;  // utf8.hpp:14 (U+2581)
 constexpr uint32_t kInvalidUnicode = 0x110000;

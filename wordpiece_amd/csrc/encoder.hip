@@ -597,9 +597,9 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       const int bc = radix_sort_pairs<uint32_t>(dst, val, t_dst, t_val, m, std::max(0, hb - bin_bits), hb, d_radix_tmp,
                                                 radix_words, st, nullptr, false, hb + 1);
       hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, bc ? t_dst : dst,
-                         bc ? t_val : val, m, d_rank, 1);
+                         bc ? t_val : val, m, d_rank, n, 1);
     } else {
-      hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, dst, val, m, d_rank, 0);
+      hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, dst, val, m, d_rank, n, 0);
     }
   };
   // (the low bits of a round-0 key are the tail of a compressed codeword stream: near-uniform digits)
@@ -645,7 +645,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
                            text_only ? d_rng_lo : nullptr, d_rng_hi, d_rng_long);
       }
       hipLaunchKernelGGL(needed_list_close_kernel, dim3(1), dim3(1), 0, st2, c->d_scalars + 4, d_ghead);
-      if (M > 0) hipLaunchKernelGGL(needed_fill_kernel, dim3(1024), dim3(kBlock), 0, st2, nl, vals);
+      if (M > 0) hipLaunchKernelGGL(needed_fill_kernel, dim3(1024), dim3(kBlock), 0, st2, nl, vals, n);
       hipLaunchKernelGGL(round0_rank_kernel, dim3(cdiv(n, kR0Tile)), dim3(kBlock), 0, st, keys, vals, n, dcode.first_len,
                          dcode.uniform_bits, (v->keep_debug || v->lcp_kasai) ? d_sa : nullptr, hd, d_lcp, d_gdepth);
       join();  // the rank store below reuses the key buffer as scratch: the searches in it must be over
@@ -866,7 +866,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   size_t n_ids = 0;
   if (n_text > 0) {
     WalkArgs wa{d_cls, n_text, d_rank, steps, c->d_tok_len, hv.unk_id, d_emit, nullptr, nullptr, nullptr,
-                hv.soft.empty() ? 1 : 0};
+                hv.soft.empty() ? 1 : 0, static_cast<int32_t>(hv.tokens.size())};
     S.anchor_mode = 0;
     if (anchors_late) {
       join();
@@ -973,6 +973,21 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     }
     S.guard_zones = static_cast<int32_t>(ar.zones.size() + aa.zones.size());
   }
+#ifdef WP_DEBUG_BOUNDS
+  {
+    unsigned int oob[kBoundSites] = {};
+    WP_HIP(hipStreamSynchronize(st));
+    WP_HIP(hipMemcpyFromSymbol(oob, HIP_SYMBOL(g_wp_oob), sizeof(oob)));
+    const unsigned int zero[kBoundSites] = {};
+    WP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wp_oob), zero, sizeof(zero)));
+    if (oob[0] | oob[1] | oob[2] | oob[3]) {
+      throw HipError("debug bounds: out-of-range addresses skipped: radix scatter " + std::to_string(oob[0]) +
+                     ", rank store " + std::to_string(oob[1]) + ", token id " + std::to_string(oob[2]) + ", list slot " +
+                     std::to_string(oob[3]));
+    }
+    S.reserved0 = 1;  // this is the bounds-checking build
+  }
+#endif
   fetch_scalars(c, 20);
   n_ids = n_text > 0 ? c->h_scalars[9] : 0;
   S.needed_after_round0 = prune ? (rounds > 1 ? S.active_per_round[1] : 0) : -1;

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(kBlock) void need_groups_kernel(const uint64_t *__r
 
 // entries of the needed groups: list position p belongs to the group g with ghead[g] <= p < ghead[g+1]
 // (ghead ascends with g: both come from one atomic) and is slot gfirst[g] + p - ghead[g]
-__global__ __launch_bounds__(kBlock) void needed_fill_kernel(NeededList out, const uint32_t *__restrict__ sorted_vals) {
+__global__ __launch_bounds__(kBlock) void needed_fill_kernel(NeededList out, const uint32_t *__restrict__ sorted_vals,
+                                                             size_t n) {
   const uint32_t *t32 = reinterpret_cast<const uint32_t *>(out.totals);
   const uint32_t n_act = t32[0], n_groups = t32[1];
   for (size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; p < n_act;
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(kBlock) void needed_fill_kernel(NeededList out, con
       if (out.ghead[md] <= p) lo = md; else hi = md;
     }
     const uint32_t k = out.gfirst[lo] + static_cast<uint32_t>(p - out.ghead[lo]);
+    if (!wp_in_bounds(k < n, kSiteListSlot)) continue;
     const uint32_t v = sorted_vals[k];
     out.slots[p] = k;
     out.vals[p] = v;

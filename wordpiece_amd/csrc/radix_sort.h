@@ -332,6 +332,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
       const KeyT kk = skeys[k];
       const uint32_t d = static_cast<uint32_t>(kk >> begin_bit) & mask;
       const size_t o = static_cast<size_t>(gbase[d]) + k;
+      if (!wp_in_bounds(o < n, kSiteRadixScatter)) continue;
       kout[o] = kk;
       vout[o] = svals[k];
       if (dout) dout[o] = static_cast<uint8_t>(static_cast<uint32_t>(kk >> next_bit) & next_mask);

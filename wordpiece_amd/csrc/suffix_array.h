@@ -263,7 +263,7 @@ constexpr int kSpItems = WP_SP_ITEMS;
 constexpr int kSpTile = kBlock * kSpItems;
 __global__ __launch_bounds__(kBlock) void scatter_pairs_kernel(const uint32_t *__restrict__ dst,
                                                                const RankEntry *__restrict__ val, size_t m,
-                                                               RankEntry *__restrict__ out, int xcd) {
+                                                               RankEntry *__restrict__ out, size_t out_n, int xcd) {
   unsigned b = blockIdx.x;
   if (xcd) {
     const unsigned nb = gridDim.x, q = nb / 8, r = nb % 8, x = b % 8;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void scatter_pairs_kernel(const uint32_t *_
   }
 #pragma unroll
   for (int j = 0; j < kSpItems; j++) {
-    if (v[j] != kRankUnchanged) out[d[j]] = v[j];
+    if (v[j] != kRankUnchanged && wp_in_bounds(d[j] < out_n, kSiteRankStore)) out[d[j]] = v[j];
   }
 }
 

@@ -31,6 +31,7 @@ struct WalkArgs {
   const uint32_t *wp_from_tile;  // with aflags: first word-prefix position >= t * kReachTile (n_text: none)
   const uint32_t *ns_from_tile;  // with aflags: first non-space position >= t * kReachTile (n_text: none)
   int all_hard;  // no spacing char occurs inside an eligible multi-char token (every sane vocabulary)
+  int32_t n_tokens;  // vocab lines (debug build: range check of the ids that come out of the step table)
 };
 
 __device__ __forceinline__ bool w_space(const WalkArgs &a, size_t p) { return a.cls[p] & kClsSpace; }
@@ -52,7 +53,8 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
     const bool prefix = w_word_prefix(a, p);
     const uint32_t r = rank_of(a.rank[p]);
     const int k = step_lookup(a.steps, r);
-    const int32_t id = prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
+    int32_t id = prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
+    if (!wp_in_bounds(id >= -1 && id < a.n_tokens, kSiteTokenId)) id = -1;
     if (id != -1) {
       a.emit[p] = id;
       p += static_cast<size_t>(a.tok_len[id]);
