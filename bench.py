@@ -32,9 +32,10 @@ import wordpiece_amd as W  # noqa: E402
 from wordpiece_amd import synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
-RADIX_BYTES_PER_ELEM = 24  # one radix pass reads and writes a 12-byte (key, index) record
+# one radix pass reads and writes a (key, index) record: 12 bytes with a 64-bit key (round 1 of this
+# build), 8 bytes with the 32-bit round-0 keys of this round (wp_stats.key_bits); radix_bytes() below
 # SA/LCP stage, algorithmic bytes per symbol besides the radix passes:
-SPLIT_BYTES = 16       # round 0 after the sort (round0_rank_kernel): keys 8 read, rank 4 + LCP 4 written
+SPLIT_BYTES = 12       # round 0 after the sort (round0_rank_kernel): keys 4 read, rank 4 + LCP 4 written
 RANK_STORE_BYTES = 32  # destination partition (4 read; 8 read + 8 written) + scatter (8 read, 4 written)
 ROUND_BYTES = 110      # rounds >= 1, per list entry: LDS sort 28 + split 50 + rank store 32
 
@@ -199,8 +200,10 @@ def main():
     ok = True
     if rank == 0:
         steps = max(args.steps, 1)
-        ms_per_step = dt_max / args.steps * 1e3
-        value = total_bytes / 1e6 / (dt_max / args.steps)
+        key_bytes = 4 if 0 < st["key_bits"] <= 32 else 8
+        RADIX_BYTES_PER_ELEM = 2 * (key_bytes + 4)
+        scatter_name = "radix_scatter_kernel<%s> (full-size tiles; the round-0 suffix sort: %d-bit keys, %d-byte records)" % (
+            "uint32, 16" if key_bytes == 4 else "uint64, 24", st["key_bits"], key_bytes + 4)
         # dominant kernel: the radix scatter pass.  Algorithmic bytes per launch = 24 B per element moved (the
         # 12-byte record read and written), - 4 B per symbol for the first pass, which makes the index column
         # up instead of reading it, + 1 B per element for the digit byte it leaves for the next pass's histogram
@@ -225,12 +228,12 @@ def main():
                        "symbols_n": st["n_total"], "n_text": st["n_text"], "vocab_in_s": st["vocab_in_s"],
                        "ids_per_step_rank0": int(n_ids), "rounds": st["rounds"],
                        "sorted_depth": st["sorted_depth"], "symbol_bits": st["symbol_bits"],
-                       "symbols_per_key": st["symbols_per_key"], "active_per_round": st["active_per_round"],
+                       "symbols_per_key": st["symbols_per_key"], "key_bits": st["key_bits"], "active_per_round": st["active_per_round"],
                        "needed_after_round0": st["needed_after_round0"],
                        "radix_launches_per_step": radix_launches // steps,
                        "id_gather": ("%s: exact-size receives on rank 0" % ("rccl" if backend == "nccl" else backend)) if distributed
                        else "none (single GPU)"},
-            "roofline": {"bound": "hbm", "kernel": "radix_scatter_kernel<uint64, 24> (full-size tiles; the round-0 suffix sort)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": scatter_name, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 4),
                          "algorithmic_bytes_per_launch": int(avg_launch_bytes)},
@@ -240,7 +243,7 @@ def main():
         # re-read of the keys: the histograms read the digit bytes)
         n_sym, act = st["n_total"], st["active_per_round"]
         passes = radix_elems / steps
-        dig = (2 * digit_bytes / steps + n_sym) if digit_bytes else 8 * passes  # written + read (+ the key builder's bytes), or the 8-byte key read
+        dig = (2 * digit_bytes / steps + n_sym) if digit_bytes else key_bytes * passes  # written + read (+ the key builder's bytes), or the key re-read
         sa_bytes = RADIX_BYTES_PER_ELEM * passes - 4 * n_sym + dig + (SPLIT_BYTES + RANK_STORE_BYTES) * n_sym + ROUND_BYTES * sum(act[1:])
         sa_ms = stage_ms.get("ms_sa", 0.0) / steps
         if sa_ms > 0:

@@ -166,10 +166,13 @@ typedef struct {
   int32_t n_devices;          /* devices that took part (wp_linear_encode_multi), else 1    */
   int32_t vocab_in_s;         /* 1: S = text . 1 . vocab as in linear.cpp:77-101; 0: S = text . 1 and
                                  the vocab comes in through the per-handle vocab structure  */
-  int32_t reserved0;
+  int32_t reserved0;          /* 1: this is the bounds-checking build (libwordpiece_amd_dbg.so)     */
   int64_t needed_after_round0; /* depth-capped mode: suffixes in tied groups that carry the key of an
                                  eligible token longer than the key — the only ones that go on to
                                  round 1 (-1: every tied group does, e.g. full depth)          */
+  int32_t key_bits;           /* bits of the codeword stream in a round-0 key; keys of up to 32 bits
+                                 are sorted as 8-byte (key, index) records, longer ones as 12-byte */
+  int32_t reserved1;
 } wp_stats;
 int wp_get_stats(const wp_vocab *v, wp_stats *out);
 

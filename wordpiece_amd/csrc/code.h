@@ -18,18 +18,22 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <type_traits>
 #include <vector>
 
 namespace wp {
 
-// 40 bits = 5 radix passes.  With the round-0 pruning (prune.h) ties cost next to nothing — only the
-// groups that carry a long token's key go on — so fewer key bits are a plain saving of passes until the
-// needed groups grow: measured on the 100 MB bench shard, ms per step / entries in round 1:
-// 63 bits 11.3 / 12 k, 56: 10.6 / 60 k, 48: 10.1 / 0.25 M, 40: 9.5 / 0.8 M, 32: 9.6 / 3.0 M, 24: 9.9 / 5.6 M.
+// 32 bits = 4 radix passes over 8-byte (key u32, index u32) records.  With the round-0 pruning (prune.h)
+// ties cost next to nothing — only the groups that carry a long token's key go on — so fewer key bits are
+// a plain saving of passes until the needed groups grow.  Measured on the 100 MB bench shard with 8-byte
+// keys in 12-byte records, ms per step / entries in round 1: 63 bits 11.3 / 12 k, 56: 10.6 / 60 k,
+// 48: 10.1 / 0.25 M, 40: 9.5 / 0.8 M, 32: 9.6 / 3.0 M, 24: 9.9 / 5.6 M; keys of up to 32 bits are stored
+// as uint32 (Key0), which makes a pass move 16 instead of 24 bytes per element.
 #ifndef WP_KEY_BITS
-#define WP_KEY_BITS 40
+#define WP_KEY_BITS 32
 #endif
 constexpr int kKeyBits = WP_KEY_BITS;  // bits of the codeword stream kept in a round-0 key (<= 63)
+using Key0 = std::conditional_t<(kKeyBits <= 32), uint32_t, uint64_t>;  // storage type of the round-0 keys
 constexpr int kMaxCodeLen = 12;  // decode table: 2^12 entries (first codeword length of a 12-bit window)
 
 struct SymbolCode {

@@ -275,7 +275,7 @@ constexpr int kKeyHalo = 64;
 __device__ __forceinline__ int key_pad(int p) { return p + (p >> 3); }
 template <typename SymT>
 __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restrict__ sym, size_t n, DevCode code,
-                                                             uint64_t *__restrict__ keys,
+                                                             Key0 *__restrict__ keys,
                                                              uint8_t *__restrict__ dig0) {
   constexpr int kSymSlots = kKeyTile + kKeyHalo;
   __shared__ uint32_t ss[kSymSlots + kSymSlots / 8 + 1];
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
     const size_t i = base + li;
     if (i < n) {
       const uint64_t k = skey[key_pad(li)];
-      keys[i] = k;  // (the values, 0..n-1, are made up by the first radix pass)
+      keys[i] = static_cast<Key0>(k);  // (the values, 0..n-1, are made up by the first radix pass)
       if (dig0) dig0[i] = static_cast<uint8_t>(k);  // first radix digit: that pass's histogram reads 1 byte per key
     }
   }

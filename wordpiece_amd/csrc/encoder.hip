@@ -562,7 +562,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   }
   S.symbols_per_key = static_cast<int32_t>(kKeyBits / std::max(1.0, code.avg_bits));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(build_keys0_kernel<SymT>), dim3(cdiv(n, kKeyTile)), dim3(kBlock), 0, st, d_sym,
-                     n, dcode, K0, DG0);
+                     n, dcode, reinterpret_cast<Key0 *>(K0), DG0);
   WP_LAUNCH_CHECK();
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[2], st));
 
@@ -609,9 +609,13 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   db.dg0_ready = DG0 != nullptr;
   // histogram by LDS atomics for the digits below this bit (near-uniform digits), by match-any ballots above
   static const int hist_atomic_bits = getenv("WP_HIST_ATOMIC_BITS") ? atoi(getenv("WP_HIST_ATOMIC_BITS")) : 16;
-  int cur = radix_sort_pairs<uint64_t>(K0, V0, K1, V1, n, 0, kKeyBits, d_radix_tmp, radix_words, st, &c->rstats, true,
-                                       code.uniform_bits ? 0 : hist_atomic_bits, db);
-  uint64_t *keys = cur ? K1 : K0;
+  // (round-0 keys of up to 32 bits live as uint32 in the first half of the 64-bit key buffers)
+  // (round-0 keys of up to 32 bits live as uint32 in the first half of the 64-bit key buffers)
+  int cur = radix_sort_pairs<Key0>(reinterpret_cast<Key0 *>(K0), V0, reinterpret_cast<Key0 *>(K1), V1, n, 0, kKeyBits,
+                                   d_radix_tmp, radix_words, st, &c->rstats, true, code.uniform_bits ? 0 : hist_atomic_bits,
+                                   db);
+  Key0 *keys = reinterpret_cast<Key0 *>(cur ? K1 : K0);
+  S.key_bits = kKeyBits;
   uint32_t *vals = cur ? V1 : V0, *other_vals = cur ? V0 : V1;
   uint32_t *slots = AS0, *other_slots = AS1;
   uint32_t *adep = AD0, *other_dep = AD1;
@@ -629,6 +633,13 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     lb.ticket = reinterpret_cast<uint32_t *>(lb.wb + tiles);
     const size_t lb_bytes = static_cast<size_t>(tiles) * 16 + 16;
     RankEntry *hd = reinterpret_cast<RankEntry *>(cur ? K0 : K1);
+    // full-depth mode: the count / prefix / apply kernels take 64-bit keys (32-bit keys are widened into the
+    // large-group key buffer, which is free during round 0)
+    auto keys64 = [&]() -> const uint64_t * {
+      if (sizeof(Key0) == 8) return reinterpret_cast<const uint64_t *>(keys);
+      hipLaunchKernelGGL(widen_keys_kernel, dim3(std::min<size_t>(cdiv(n, kBlock), 8192)), dim3(kBlock), 0, st, keys, LK1, n);
+      return LK1;
+    };
     if (prune) {
       // Depth-capped mode: the groups that have to go on are found from the vocabulary (prune.h) and appended
       // to the active list by the kernel that finds them — on the side stream (a few thousand waves of
@@ -651,13 +662,14 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       join();  // the rank store below reuses the key buffer as scratch: the searches in it must be over
     } else if (fused_rerank) {
       WP_HIP(hipMemsetAsync(lb.wa, 0, lb_bytes, st));
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_fused_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_fused_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys64(),
                          vals, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), n, tiles,
                          lb, d_sym, static_cast<const RankEntry *>(nullptr), static_cast<const uint32_t *>(nullptr), n,
                          dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp, slots, other_vals, AG, adep,
                          d_ghead, d_gdepth, static_cast<uint32_t *>(nullptr), c->d_scalars + 4);
     } else {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<true>), dim3(tiles), dim3(kBlock), 0, st, keys, vals, n,
+      const uint64_t *k64 = keys64();
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<true>), dim3(tiles), dim3(kBlock), 0, st, k64, vals, n,
                          static_cast<const uint32_t *>(nullptr), static_cast<const RankEntry *>(nullptr),
                          static_cast<const uint32_t *>(nullptr), n, dcode.first_len, dcode.uniform_bits, rule, d_tdep,
                          d_agg);
@@ -665,7 +677,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
                          d_chunk_agg);
       hipLaunchKernelGGL(rerank_prefix_kernel, dim3(cdiv(tiles, kRrChunk)), dim3(kBlock), 0, st, d_agg, d_chunk_agg,
                          tiles);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys,
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, k64,
                          vals, static_cast<const uint32_t *>(nullptr), static_cast<const uint32_t *>(nullptr), d_tdep,
                          n, d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rule, d_sa, hd, d_lcp,
                          slots, other_vals, AG, adep, d_ghead, d_gdepth, c->d_scalars + 4);
@@ -733,7 +745,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
                          avals, adep, d_lg_head, d_lg_off, static_cast<uint32_t>(n_large_groups), n_large, d_rank, n, rb,
                          K1, LV0, LPOS);
       const int lc = radix_sort_pairs<uint64_t>(K1, LV0, LK1, LV1, n_large, 0, rb + lgb, d_radix_tmp, radix_words, st2,
-                                                &c->rstats);
+                                                nullptr);  // (the roofline statistics describe the round-0 sort only)
       hipLaunchKernelGGL(large_writeback_kernel, dim3(std::min<size_t>(cdiv(n_large, kBlock), 8192)), dim3(kBlock), 0,
                          st2, lc ? LK1 : K1, lc ? LV1 : LV0, LPOS, n_large, AG, rb, skeys, svals);
       join();

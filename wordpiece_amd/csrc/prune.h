@@ -62,11 +62,11 @@ __device__ inline bool token_key(const uint32_t *__restrict__ cps, uint32_t len,
   return overflow;
 }
 
-__device__ __forceinline__ size_t key_lower_bound(const uint64_t *__restrict__ keys, size_t n, uint64_t key) {
+__device__ __forceinline__ size_t key_lower_bound(const Key0 *__restrict__ keys, size_t n, uint64_t key) {
   size_t lo = 0, hi = n;
   while (lo < hi) {
     const size_t md = (lo + hi) >> 1;
-    if (keys[md] < key) lo = md + 1; else hi = md;
+    if (static_cast<uint64_t>(keys[md]) < key) lo = md + 1; else hi = md;
   }
   return lo;
 }
@@ -101,7 +101,7 @@ struct NeededList {
 };
 
 template <typename SymT>
-__global__ __launch_bounds__(kBlock) void need_groups_kernel(const uint64_t *__restrict__ keys,
+__global__ __launch_bounds__(kBlock) void need_groups_kernel(const Key0 *__restrict__ keys,
                                                              const uint32_t *__restrict__ vals, size_t n,
                                                              const SymT *__restrict__ sym,
                                                              const uint32_t *__restrict__ vocab_cps,

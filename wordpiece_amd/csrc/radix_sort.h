@@ -33,7 +33,10 @@ struct RadixCfg {
 #ifndef WP_RADIX_ITEMS64
 #define WP_RADIX_ITEMS64 24  // 6144-key tiles: 74 KB of LDS staging, two workgroups per CU (16 / 20 / 24: 13.78 / 13.73 / 13.69 ms)
 #endif
-  static constexpr int kItems = sizeof(KeyT) == 8 ? WP_RADIX_ITEMS64 : 16;
+#ifndef WP_RADIX_ITEMS32
+#define WP_RADIX_ITEMS32 16
+#endif
+  static constexpr int kItems = sizeof(KeyT) == 8 ? WP_RADIX_ITEMS64 : WP_RADIX_ITEMS32;
   static constexpr int kTile = kBlock * kItems;
   // Inputs of up to kSmallN elements (mark / step lists, the large groups of a doubling round) use
   // tiles of kSmallItems per thread: a full-size tile takes ~70 us from first load to last store, and

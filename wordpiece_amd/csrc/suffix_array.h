@@ -492,6 +492,15 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
                                hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, nullptr, rule);
 }
 
+// full-depth mode with 32-bit round-0 keys: the count / prefix / apply kernels below take 64-bit keys
+__global__ __launch_bounds__(kBlock) void widen_keys_kernel(const Key0 *__restrict__ in, uint64_t *__restrict__ out,
+                                                            size_t n) {
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<size_t>(gridDim.x) * kBlock) {
+    out[i] = static_cast<uint64_t>(in[i]);
+  }
+}
+
 // ---- round 0 in the depth-capped mode: ranks and LCPs only ---------------------------------------------
 // With the pruning of prune.h the next active list is written by the kernel that finds the needed
 // groups, so round 0 needs no counting pass, no tile prefix and no compaction: one streaming kernel turns
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
 // binary search in the sorted keys for the rare group that is longer than that.
 constexpr int kR0Rounds = 16;  // 1024 entries per wave: the look behind the wave is paid once per 1024 entries
 constexpr int kR0Tile = kBlock * kR0Rounds;
-__global__ __launch_bounds__(kBlock) void round0_rank_kernel(const uint64_t *__restrict__ keys,
+__global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restrict__ keys,
                                                              const uint32_t *__restrict__ vals, size_t n,
                                                              const uint8_t *__restrict__ first_len, int uniform_bits,
                                                              uint32_t *__restrict__ sa_dbg, RankEntry *__restrict__ hd,
@@ -518,12 +527,12 @@ __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const uint64_t *__r
 #pragma unroll
   for (int r = 0; r < kR0Rounds; r++) {
     const size_t k = wave_base + static_cast<size_t>(r) * kWave + lane;
-    me[r] = k < n ? keys[k] : ~0ull;
+    me[r] = k < n ? static_cast<uint64_t>(keys[k]) : ~0ull;  // (registers hold 64 bits: ~0 is never a key)
   }
   const bool have_front = wave_base < n && wave_base >= 1 + static_cast<size_t>(lane);
-  const uint64_t front = have_front ? keys[wave_base - 1 - lane] : ~0ull;  // lane l: the key l + 1 entries in front
+  const uint64_t front = have_front ? static_cast<uint64_t>(keys[wave_base - 1 - lane]) : ~0ull;  // lane l: the key l + 1 entries in front
   const size_t after_idx = wave_base + static_cast<size_t>(kWave) * kR0Rounds;
-  const uint64_t after = after_idx < n ? keys[after_idx] : ~0ull;  // (wave-uniform address: one broadcast load)
+  const uint64_t after = after_idx < n ? static_cast<uint64_t>(keys[after_idx]) : ~0ull;  // (wave-uniform address: one broadcast load)
   if (uniform_bits <= 0) {
     for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
       reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
