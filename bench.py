@@ -131,11 +131,29 @@ def main():
     # one-GPU box; launch through torch.distributed.run --nproc-per-node 1)
     distributed = world > 1 or os.environ.get("WP_BENCH_FORCE_GATHER") == "1"
     if distributed:
+        import contextlib
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+
+        @contextlib.contextmanager
+        def stdout_to_stderr():
+            """RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for
+            the ONE JSON line (file-descriptor level: the banner comes from the C library)."""
+            sys.stdout.flush()
+            saved = os.dup(1)
+            try:
+                os.dup2(2, 1)
+                yield
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
+
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()  # (brings the communicator up here, banner included)
 
     vocab_h = W.Vocab(vocab, device=dev_index)
     vocab_h.set_option(W.WP_OPT_STAGE_TIMING, 1)
@@ -204,9 +222,11 @@ def main():
         RADIX_BYTES_PER_ELEM = 2 * (key_bytes + 4)
         scatter_name = "radix_scatter_kernel<%s> (full-size tiles; the round-0 suffix sort: %d-bit keys, %d-byte records)" % (
             "uint32, 16" if key_bytes == 4 else "uint64, 24", st["key_bits"], key_bytes + 4)
-        # dominant kernel: the radix scatter pass.  Algorithmic bytes per launch = 24 B per element moved (the
-        # 12-byte record read and written), - 4 B per symbol for the first pass, which makes the index column
-        # up instead of reading it, + 1 B per element for the digit byte it leaves for the next pass's histogram
+        ms_per_step = dt_max / args.steps * 1e3
+        value = total_bytes / 1e6 / (dt_max / args.steps)
+        # dominant kernel: the radix scatter pass.  Algorithmic bytes per launch = the (key, index) record read and
+        # written per element moved (16 B with 32-bit keys), - 4 B per symbol for the first pass, which makes the index
+        # column up instead of reading it, + 1 B per element for the digit byte it leaves for the next pass's histogram
         avg_launch_ms = radix_ms / max(radix_launches, 1)
         avg_launch_bytes = (RADIX_BYTES_PER_ELEM * radix_elems - 4 * st["n_total"] * args.steps + digit_bytes) / max(radix_launches, 1)
         achieved = avg_launch_bytes / 1e9 / (avg_launch_ms / 1e3) if avg_launch_ms > 0 else 0.0
