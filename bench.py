@@ -220,8 +220,9 @@ def main():
         steps = max(args.steps, 1)
         key_bytes = 4 if 0 < st["key_bits"] <= 32 else 8
         RADIX_BYTES_PER_ELEM = 2 * (key_bytes + 4)
-        scatter_name = "radix_scatter_kernel<%s> (full-size tiles; the round-0 suffix sort: %d-bit keys, %d-byte records)" % (
-            "uint32, 16" if key_bytes == 4 else "uint64, 24", st["key_bits"], key_bytes + 4)
+        scatter_name = "radix_scatter_kernel<%s> (full-size tiles: the %d passes of the round-0 suffix sort over %d-bit keys%s; %d-byte records)" % (
+            "uint32, 16" if key_bytes == 4 else "uint64, 24", (st["key_bits"] + 7) // 8, st["key_bits"],
+            " and the destination partition of the rank store" if key_bytes == 4 else "", key_bytes + 4)
         ms_per_step = dt_max / args.steps * 1e3
         value = total_bytes / 1e6 / (dt_max / args.steps)
         # dominant kernel: the radix scatter pass.  Algorithmic bytes per launch = the (key, index) record read and
@@ -264,7 +265,8 @@ def main():
         n_sym, act = st["n_total"], st["active_per_round"]
         passes = radix_elems / steps
         dig = (2 * digit_bytes / steps + n_sym) if digit_bytes else key_bytes * passes  # written + read (+ the key builder's bytes), or the key re-read
-        sa_bytes = RADIX_BYTES_PER_ELEM * passes - 4 * n_sym + dig + (SPLIT_BYTES + RANK_STORE_BYTES) * n_sym + ROUND_BYTES * sum(act[1:])
+        store = RANK_STORE_BYTES - (16 if key_bytes == 4 else 0)  # (the partition scatter's 16 B are inside `passes` then)
+        sa_bytes = RADIX_BYTES_PER_ELEM * passes - 4 * n_sym + dig + (SPLIT_BYTES + store) * n_sym + ROUND_BYTES * sum(act[1:])
         sa_ms = stage_ms.get("ms_sa", 0.0) / steps
         if sa_ms > 0:
             out["sa_lcp_stage"] = {"algorithmic_bytes": int(sa_bytes), "ms": round(sa_ms, 3),

@@ -594,8 +594,11 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     if (bin_bits > 0 && m >= (1u << 22)) {
       const int hb = bit_length(n - 1);
       // (the top bits of a text position are uniformly distributed: histogram by LDS atomics)
+      // (with 32-bit round-0 keys this is the same kernel as the passes of the suffix sort — 8-byte records —
+      // and its full-size launch is part of the same roofline statistics)
       const int bc = radix_sort_pairs<uint32_t>(dst, val, t_dst, t_val, m, std::max(0, hb - bin_bits), hb, d_radix_tmp,
-                                                radix_words, st, nullptr, false, hb + 1);
+                                                radix_words, st, (sizeof(Key0) == 4 && m == n) ? &c->rstats : nullptr, false,
+                                                hb + 1);
       hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, bc ? t_dst : dst,
                          bc ? t_val : val, m, d_rank, n, 1);
     } else {
