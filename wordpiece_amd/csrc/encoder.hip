@@ -428,7 +428,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
            *d_emit_tmp = nullptr;
   int32_t *d_lcp = nullptr, *d_mid = nullptr, *d_rf = nullptr, *d_rb = nullptr;
   RerankAgg *d_agg = nullptr, *d_chunk_agg = nullptr;
-  uint32_t *d_ghead = nullptr, *d_large_id = nullptr, *d_large_off = nullptr, *d_gscan_tmp = nullptr, *d_lg_head = nullptr,
+  uint32_t *d_ghead = nullptr, *d_large_id = nullptr, *d_large_off = nullptr, *d_lg_head = nullptr,
            *d_lg_off = nullptr, *LV0 = nullptr,
            *LV1 = nullptr, *LPOS = nullptr;
   uint64_t *LK1 = nullptr;
@@ -463,7 +463,6 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     d_ghead = ar.take<uint32_t>(n / 2 + 4);
     d_large_id = ar.take<uint32_t>(n / 2 + 4);
     d_large_off = ar.take<uint32_t>(n / 2 + 4);
-    d_gscan_tmp = ar.take<uint32_t>(cdiv(n / 2 + 4, kScanTile) + 8);
     d_lg_head = ar.take<uint32_t>(n / kLsMaxGroup + 4);
     d_lg_off = ar.take<uint32_t>(n / kLsMaxGroup + 4);
     LK1 = ar.take<uint64_t>(n);
@@ -576,13 +575,10 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   auto classify_groups = [&](size_t list_len) {
     if (list_len <= static_cast<size_t>(kLsMaxGroup)) return false;  // no group can be large
     const size_t cap = list_len / 2 + 1;  // a group has >= 2 entries
-    hipLaunchKernelGGL(group_classify_kernel, dim3(std::min<size_t>(cdiv(cap, kBlock), 4096)), dim3(kBlock), 0, st2, d_ghead,
-                       c->d_scalars + 5, d_large_id, d_large_off, cap);
-    device_exclusive_scan(d_large_id, d_large_id, cap, d_gscan_tmp, c->d_scalars + 6, st2, c->d_scalars + 5);
-    device_exclusive_scan(d_large_off, d_large_off, cap, d_gscan_tmp, c->d_scalars + 7, st2, c->d_scalars + 5);
-    hipLaunchKernelGGL(large_table_kernel, dim3(std::min<size_t>(cdiv(cap, kBlock), 4096)), dim3(kBlock), 0, st2,
-                       d_ghead, c->d_scalars + 5, d_large_id, d_large_off, c->d_scalars + 6, c->d_scalars + 7,
-                       d_lg_head, d_lg_off);
+    WP_HIP(hipMemsetAsync(c->d_scalars + 6, 0, 2 * sizeof(uint32_t), st2));
+    hipLaunchKernelGGL(large_groups_kernel, dim3(std::min<size_t>(cdiv(cap, kBlock), 2048)), dim3(kBlock), 0, st2, d_ghead,
+                       c->d_scalars + 5, reinterpret_cast<unsigned long long *>(c->d_scalars + 6), d_lg_head, d_lg_off);
+    hipLaunchKernelGGL(large_groups_close_kernel, dim3(1), dim3(1), 0, st2, c->d_scalars + 6, d_lg_off);
     return true;
   };
   // rank[dst[k]] = val[k].  Random 4-byte stores leave the L2s as partial lines; one radix pass over

@@ -31,26 +31,32 @@ constexpr int kLsBits = 10;
 constexpr int kLsBins = 1 << kLsBits;
 constexpr int kLsGroupBits = 12;  // local group number < kLsCap
 
-// group g is [ghead[g], ghead[g+1]); large[g] = size > kLsMaxGroup; the exclusive scans of
-// large[] (dense number of the large group) and of the large sizes (offset in the large list)
-// are produced by device_exclusive_scan on the two arrays written here.
-__global__ __launch_bounds__(kBlock) void group_classify_kernel(const uint32_t *__restrict__ ghead,
-                                                                const uint32_t *__restrict__ n_groups_dev,
-                                                                uint32_t *__restrict__ large_flag,
-                                                                uint32_t *__restrict__ large_size, size_t cap) {
-  // grid-stride over the groups that exist (the scans behind this kernel stop at n_groups too)
-  const size_t ng = min(cap, static_cast<size_t>(*n_groups_dev));
+// Table of the large groups (size > kLsMaxGroup) of the list: lg_head[i] = list position of the i-th
+// large group, lg_off[i] = its offset in the large list, lg_off[n_large_groups] = n_large.  Large groups
+// are few, so the table is appended to by atomics instead of two device-wide scans: one 64-bit atomic
+// hands out the table index (low word) and the offset (high word) together, so lg_off ascends with the
+// index whatever order the groups arrive in (the extract kernel searches lg_off; nothing needs lg_head
+// sorted).  counters: two adjacent uint32 {n_large_groups, n_large}, zeroed by the caller.
+__global__ __launch_bounds__(kBlock) void large_groups_kernel(const uint32_t *__restrict__ ghead,
+                                                              const uint32_t *__restrict__ n_groups_dev,
+                                                              unsigned long long *__restrict__ counters,
+                                                              uint32_t *__restrict__ lg_head,
+                                                              uint32_t *__restrict__ lg_off) {
+  const size_t ng = *n_groups_dev;
   for (size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; g < ng;
        g += static_cast<size_t>(gridDim.x) * kBlock) {
-    uint32_t f = 0, sz = 0;
-    const uint32_t s = ghead[g + 1] - ghead[g];
+    const uint32_t h = ghead[g];
+    const uint32_t s = ghead[g + 1] - h;
     if (s > kLsMaxGroup) {
-      f = 1;
-      sz = s;
+      const unsigned long long got = atomicAdd(counters, (static_cast<unsigned long long>(s) << 32) | 1ull);
+      const uint32_t i = static_cast<uint32_t>(got);
+      lg_head[i] = h;
+      lg_off[i] = static_cast<uint32_t>(got >> 32);
     }
-    large_flag[g] = f;
-    large_size[g] = sz;
   }
+}
+__global__ void large_groups_close_kernel(const uint32_t *__restrict__ counters, uint32_t *__restrict__ lg_off) {
+  lg_off[counters[0]] = counters[1];
 }
 
 // tuning aid (WP_GROUP_STATS=1): entries of the active list by group size class
@@ -63,30 +69,6 @@ __global__ __launch_bounds__(kBlock) void group_stats_kernel(const uint32_t *__r
   const int c = s <= 2 ? 0 : s <= 4 ? 1 : s <= 8 ? 2 : s <= 16 ? 3 : s <= 32 ? 4 : s <= 64 ? 5 : s <= 256 ? 6 : s <= 2048 ? 7 : 8;
   atomicAdd(&out[c], static_cast<unsigned long long>(s));
   atomicAdd(&out[9 + c], 1ull);
-}
-
-// Dense table of the large groups (after the two scans of group_classify's arrays):
-// lg_head[i] = list position of the i-th large group, lg_off[i] = its offset in the large list,
-// lg_off[n_large_groups] = n_large.
-__global__ __launch_bounds__(kBlock) void large_table_kernel(const uint32_t *__restrict__ ghead,
-                                                             const uint32_t *__restrict__ n_groups_dev,
-                                                             const uint32_t *__restrict__ large_id,
-                                                             const uint32_t *__restrict__ large_off,
-                                                             const uint32_t *__restrict__ n_large_groups_dev,
-                                                             const uint32_t *__restrict__ n_large_dev,
-                                                             uint32_t *__restrict__ lg_head,
-                                                             uint32_t *__restrict__ lg_off) {
-  const size_t ng = *n_groups_dev;
-  for (size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; g < ng;
-       g += static_cast<size_t>(gridDim.x) * kBlock) {
-    const uint32_t h = ghead[g];
-    if (ghead[g + 1] - h > kLsMaxGroup) {
-      const uint32_t i = large_id[g];
-      lg_head[i] = h;
-      lg_off[i] = large_off[g];
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) lg_off[*n_large_groups_dev] = *n_large_dev;
 }
 
 // entries of large groups -> (key, val, list position) in the large list; key = dense large-group

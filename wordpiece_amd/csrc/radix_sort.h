@@ -235,6 +235,37 @@ __global__ __launch_bounds__(kRadixBins) void radix_apply_kernel(uint32_t *__res
   }
 }
 
+// Small inputs (<= kRadixSmallN elements: at most 32 chunks): spine and apply in one launch — every
+// workgroup sums the few chunk rows itself (digit totals and the part in front of its own chunk), scans the
+// 256 totals, and rewrites its chunk of the table.  One launch less per pass, and these sorts are
+// bound by launch latency, not by bytes.
+__global__ __launch_bounds__(kRadixBins) void radix_apply_small_kernel(uint32_t *__restrict__ table,
+                                                                       const uint32_t *__restrict__ chunk_sums,
+                                                                       unsigned nchunks, unsigned ntiles) {
+  // (one thread per digit and a block scan of kBlock values: used with 8-bit digits only)
+  __shared__ uint32_t ssum[8];
+  const int d = threadIdx.x;
+  uint32_t total = 0, before = 0;
+  for (unsigned c = 0; c < nchunks; c++) {
+    const uint32_t v = chunk_sums[static_cast<size_t>(c) * kRadixBins + d];
+    total += v;
+    if (c < blockIdx.x) before += v;
+  }
+  uint32_t all;
+  uint32_t run = block_excl_sum(total, ssum, all) + before;
+  const unsigned t0 = blockIdx.x * kColChunk, t1 = min(ntiles, t0 + kColChunk);
+  for (unsigned t = t0; t < t1; t += kSpineBatch) {
+    uint32_t v[kSpineBatch];
+#pragma unroll
+    for (int j = 0; j < kSpineBatch; j++) v[j] = t + j < t1 ? table[static_cast<size_t>(t + j) * kRadixBins + d] : 0u;
+#pragma unroll
+    for (int j = 0; j < kSpineBatch; j++) {
+      if (t + j < t1) table[static_cast<size_t>(t + j) * kRadixBins + d] = run;
+      run += v[j];
+    }
+  }
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Mapping workgroup b to
 // tile (b % 8) * (ntiles / 8) + b / 8 gives every XCD a contiguous range of tiles: consecutive tiles
 // append to the same digit runs, so the partial 128-byte lines at the run ends meet in one L2 and
@@ -467,8 +498,12 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT, RadixCfg<KeyT>::kItems>), dim3(ntiles),
                          dim3(kBlock), 0, st, ki, dgi, n, b, mask, table, chunk_sums, b < uniform_low_bits ? 1 : 0);
     }
-    hipLaunchKernelGGL(radix_spine_kernel, dim3(1), dim3(kSpineThreads), 0, st, chunk_sums, chunk_pre, nchunks);
-    hipLaunchKernelGGL(radix_apply_kernel, dim3(nchunks), dim3(kRadixBins), 0, st, table, chunk_pre, ntiles);
+    if (small && kRadixBins == kBlock) {
+      hipLaunchKernelGGL(radix_apply_small_kernel, dim3(nchunks), dim3(kRadixBins), 0, st, table, chunk_sums, nchunks, ntiles);
+    } else {
+      hipLaunchKernelGGL(radix_spine_kernel, dim3(1), dim3(kSpineThreads), 0, st, chunk_sums, chunk_pre, nchunks);
+      hipLaunchKernelGGL(radix_apply_kernel, dim3(nchunks), dim3(kRadixBins), 0, st, table, chunk_pre, ntiles);
+    }
     if (stats) stats->spans.begin(st);
     const uint32_t *vsrc = identity_vals ? static_cast<const uint32_t *>(nullptr) : vi;
     if (small) {
