@@ -569,7 +569,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   // round 0 only keeps the tied groups that carry the key of a long eligible token (prune.h)
   static const bool env_no_prune = env_flag("WP_NO_PRUNE");
   const bool prune = !full && !env_no_prune && (M > 0 || text_only);
-  DepthRule rule{need_depth, full ? 1 : 0, nullptr, 0};
+  const DepthRule rule{need_depth, full ? 1 : 0};
   // after every rerank: classify the new groups (large ones take the global path next round)
   // (runs on the side stream, next to the rank scatter)
   auto classify_groups = [&](size_t list_len) {

@@ -37,19 +37,9 @@ struct RerankAgg {
 struct DepthRule {
   uint32_t need;  // a tied group retires once its depth reaches this (depth-capped mode)
   int full;       // 1: only singletons retire (true suffix array)
-  // round 0, depth-capped mode (prune.h): need_map[k] != 0 iff sorted position k lies in a group that
-  // carries the key of an eligible token longer than the key; all other groups retire at once
-  const uint8_t *need_map;
-  int sa_needed_only;  // round 0: keep SA entries only for the slots of needed groups (text-only layout)
 };
 
-template <bool ROUND0>
-__device__ __forceinline__ bool rr_stays_active(const DepthRule &rule, uint32_t nd, size_t k) {
-  if (rule.full) return true;
-  if (nd >= rule.need) return false;
-  if (ROUND0 && rule.need_map) return rule.need_map[k] != 0;
-  return true;
-}
+__device__ __forceinline__ bool rr_stays_active(const DepthRule &rule, uint32_t nd) { return rule.full || nd < rule.need; }
 
 __device__ __forceinline__ void rr_flags(const uint64_t *__restrict__ keys, size_t m, size_t k, bool &flag,
                                          bool &single) {
@@ -93,14 +83,7 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
     bool f = false, sg = true, act = false;
     if (k < m) {
       rr_flags(keys, m, k, f, sg);
-      if (ROUND0 && rule.need_map) {
-        // pruned round 0: only the entries of needed groups can stay, only they need a depth here (the
-        // apply pass computes the depths it stores itself); nothing goes through tdep
-        if (!sg && rule.need_map[k]) {
-          const uint32_t nd = static_cast<uint32_t>(count_key_symbols(keys[k], kKeyBits, s_fl, uniform_bits));
-          act = nd < rule.need;
-        }
-      } else if (!sg) {
+      if (!sg) {
         uint32_t nd;
         if (ROUND0) {
           nd = static_cast<uint32_t>(count_key_symbols(keys[k], kKeyBits, s_fl, uniform_bits));
@@ -113,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
           nd = min(d + dj, 0x7fffffffu);
         }
         tdep[k] = nd;
-        act = rr_stays_active<ROUND0>(rule, nd, k);
+        act = rr_stays_active(rule, nd);
       }
     }
     const uint64_t bf = __ballot(f), ba = __ballot(act), bh = __ballot(f && act);
@@ -320,13 +303,7 @@ __device__ __forceinline__ void rr_first_half(RrTile &T, const uint64_t *__restr
       const uint64_t next = k + 1 < m ? keys[k + 1] : ~me;
       f = prev != me;
       sg = f && next != me;
-      if (ROUND0 && rule.need_map) {
-        // pruned round 0: a depth is needed for the entries that may stay and for the heads of tied groups
-        // (kept at gdepth[] for the rounds that double through them); computed here, no tdep round trip
-        const bool needed = !sg && rule.need_map[k];
-        if (needed || (f && !sg)) nd = static_cast<uint32_t>(count_key_symbols(me, kKeyBits, s_fl, uniform_bits));
-        act = needed && nd < rule.need;
-      } else if (!sg) {
+      if (!sg) {
         if (!OWN_DEPTH) {
           nd = tdep[k];
         } else if (ROUND0) {
@@ -337,7 +314,7 @@ __device__ __forceinline__ void rr_first_half(RrTile &T, const uint64_t *__restr
           const uint32_t dj = r2 ? gdepth_in[r2 - 1u] : 0u;
           nd = min(d + dj, 0x7fffffffu);
         }
-        act = rr_stays_active<ROUND0>(rule, nd, k);
+        act = rr_stays_active(rule, nd);
       }
       if (ROUND0) {
         nd = min(nd, 0xffffu);
@@ -373,7 +350,7 @@ __device__ __forceinline__ void rr_second_half(const RrTile &T, const uint64_t *
                                                uint32_t *__restrict__ nslots, uint32_t *__restrict__ nvals,
                                                uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep,
                                                uint32_t *__restrict__ ghead, uint32_t *__restrict__ gdepth,
-                                               uint32_t *__restrict__ gd, const DepthRule &rule) {
+                                               uint32_t *__restrict__ gd) {
   const int lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
   // rounds >= 1: does the group of the carried head continue the old group of the entry before it?
@@ -398,9 +375,9 @@ __device__ __forceinline__ void rr_second_half(const RrTile &T, const uint64_t *
       const uint32_t v = vals[k];
       const uint32_t x = ROUND0 ? static_cast<uint32_t>(k) : slots[k];
       const uint32_t head_slot = ROUND0 ? static_cast<uint32_t>(head) : slots[head];
-      // the suffix array itself is only kept for debug fetches / the Kasai kernel, and (text-only layout)
-      // for the slots of the groups whose long tokens are located in it afterwards
-      if (sa && !(ROUND0 && rule.sa_needed_only && !rule.need_map[k])) sa[x] = v;
+      // the suffix array itself is only kept for debug fetches / the Kasai kernel, and (text-only layout,
+      // rounds >= 1) for the slots of the groups whose long tokens are located in it afterwards
+      if (sa) sa[x] = v;
       // new rank entry of suffix v, scattered to the rank table afterwards.  In rounds >= 1 the
       // first subgroup of an old group keeps its rank (its head is the old head): left unchanged.
       bool changed = true;
@@ -489,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     head1 = max(head1, s_last[i]);
   }
   rr_second_half<SymT, ROUND0>(T, keys, m, wave_base, ea, eh, head1, vals, slots, adep, sym, n, s_fl, uniform_bits, sa,
-                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, nullptr, rule);
+                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, nullptr);
 }
 
 // full-depth mode with 32-bit round-0 keys: the count / prefix / apply kernels below take 64-bit keys
@@ -710,7 +687,7 @@ __global__ __launch_bounds__(kBlock) void rerank_fused_kernel(
     head1 = max(head1, s_last[i]);
   }
   rr_second_half<SymT, ROUND0>(T, keys, m, wave_base, ea, eh, head1, vals, slots, adep, sym, n, s_fl, uniform_bits, sa,
-                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, ROUND0 ? nullptr : gd, rule);
+                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, ROUND0 ? nullptr : gd);
 }
 
 __global__ __launch_bounds__(kBlock) void gdepth_store_kernel(const uint32_t *__restrict__ gd,
