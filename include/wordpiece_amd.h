@@ -71,7 +71,9 @@ int wp_linear_encode_device(wp_vocab *v, const void *d_utf8, size_t nbytes,
  * per entry of `devices` (HIP ordinals; an ordinal may repeat), balanced by code points; every
  * shard is encoded on its device by its own host thread against the replicated vocabulary, and the
  * ids are downloaded in shard order into one host buffer (free with wp_free).
- * devices == NULL: the first n_devices visible GPUs (n_devices <= 0: all of them). */
+ * devices == NULL: the first n_devices visible GPUs (n_devices <= 0: all of them).
+ * A vocabulary that holds whitespace inside a token can match across a cut (the reference's chunking
+ * shares the caveat): such inputs are encoded in one piece on the first device of the list. */
 int wp_linear_encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const int *devices,
                            int n_devices, int32_t **ids, size_t *n_ids);
 

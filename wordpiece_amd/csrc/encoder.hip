@@ -1450,8 +1450,12 @@ std::vector<size_t> shard_cuts(const char *utf8, size_t nbytes, int parts) {
 // One shard per entry of `devices` (ordinals may repeat: several contexts on one GPU), one host thread
 // per shard for upload + device path, then every shard's ids are downloaded straight to their place in
 // one pinned host block (exact sizes, no padded gather).
-void encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const std::vector<int> &devices, int32_t **ids,
+void encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const std::vector<int> &devices_in, int32_t **ids,
                   size_t *n_ids) {
+  // a vocabulary with whitespace inside a token can match across a cut (the reference's own chunking has the
+  // same caveat): such a text stays in one piece on the first device
+  const std::vector<int> devices = v->hv.space_in_token ? std::vector<int>(devices_in.begin(), devices_in.begin() + 1)
+                                                        : devices_in;
   const int G = static_cast<int>(devices.size());
   const auto t_all = wp_clock::now();
   if (v->multi.size() < static_cast<size_t>(G)) v->multi.resize(static_cast<size_t>(G));

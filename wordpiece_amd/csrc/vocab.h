@@ -141,6 +141,8 @@ struct HostVocab {
     return "";
   }
 
+  bool space_in_token = false;  // an eligible multi-char token holds a space: a match can reach across whitespace,
+                                // so the text must not be cut into independent shards (SURVEY 8e caveat, Q13)
   bool low_cp = false;  // some token holds code point 0 or 1 (1 is the separator of S, linear.cpp:92,99):
                         // such vocabularies always go through the reference's S = text . 1 . vocab layout
 
@@ -154,6 +156,7 @@ struct HostVocab {
     longest = 1;
     n_dup_eligible = 0;
     low_cp = false;
+    space_in_token = false;
     std::map<std::pair<bool, std::vector<uint32_t>>, int> seen;
     std::vector<uint32_t> starts(tokens.size());
     std::vector<size_t> elig;
@@ -171,6 +174,7 @@ struct HostVocab {
         if (t.word.size() > 1) {
           for (uint32_t c : t.word) {
             if (is_spacing_char(c)) soft.push_back(c);
+            if (is_space(c)) space_in_token = true;
           }
         }
       }
