@@ -1,10 +1,12 @@
-// test_word_piece.cpp — C++ known-answer test of word_piece::linear::* (include/word_piece.hpp) on
-// the GPU path, shaped like the reference's tests/tests.cpp: check(text, vocab, expected) for the
-// vectors of tests.cpp:137-217 (unknown id = -1, none of these vocabularies holds "[UNK]"), plus
-// the error behaviour of the API.  The differential half of the reference's test (Linear == Fast)
-// has no counterpart here (fast:: is out of scope); the Python parity suite diffs against the
-// CPU oracle instead.  Built by wordpiece_amd/build.py, run by tests/test_gpu_api.py.
+// test_word_piece.cpp — C++ known-answer test of word_piece::linear::* and word_piece::fast::*
+// (include/word_piece.hpp) on the GPU path, shaped like the reference's tests/tests.cpp:
+// check(text, vocab, expected) asserts BOTH algorithms against the vectors of tests.cpp:137-217 (unknown id
+// = -1, none of these vocabularies holds "[UNK]") as tests.cpp:80-88 does, check(text, vocab) asserts
+// linear == fast (tests.cpp:90-97) on a small random-split grid (tests.cpp:219-246, own generator), plus the
+// error behaviour of the API.  Built by wordpiece_amd/build.py, run by tests/test_gpu_api.py.
 #include <iostream>
+#include <random>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -24,6 +26,38 @@ static void check(const std::string &s, const std::vector<std::string> &vocab, c
     for (int x : expected) std::cout << ' ' << x;
     std::cout << std::endl;
     throw std::runtime_error("Comparison failed");
+  }
+  if (word_piece::fast::encode(s, vocab) != expected) throw std::runtime_error("Comparison failed (fast) for \"" + s + "\"");
+}
+
+static void check(const std::string &s, const std::vector<std::string> &vocab) {  // tests.cpp:90-97
+  ++total_checks;
+  if (word_piece::linear::encode(s, vocab) != word_piece::fast::encode(s, vocab)) {
+    throw std::runtime_error("linear != fast for \"" + s + "\"");
+  }
+}
+
+static void testRandomSplit() {  // tests.cpp:219-246 in miniature
+  std::mt19937 rnd(17);
+  for (size_t text_len : {10u, 40u, 150u, 300u}) {
+    for (size_t parts : {2u, 7u, 30u}) {
+      for (int positive = 0; positive < 2; positive++) {
+        std::string s;
+        for (size_t i = 0; i < text_len; i++) s.push_back(static_cast<char>('a' + rnd() % 26));
+        std::set<size_t> borders{text_len};
+        while (borders.size() < std::min(parts, text_len)) borders.insert(1 + rnd() % (text_len - 1));
+        std::set<std::string> res;
+        size_t start = 0;
+        for (size_t b : borders) {
+          if (start == 0) res.insert(s.substr(0, b));
+          res.insert("##" + s.substr(start, b - start));
+          start = b;
+        }
+        std::vector<std::string> vocab(res.begin(), res.end());
+        if (!positive) vocab.erase(vocab.begin());
+        if (!vocab.empty()) check(s, vocab);
+      }
+    }
   }
 }
 
@@ -92,5 +126,7 @@ int main() {
   testMaxMatch();
   testUtf8();
   testErrors();
+  std::cout << "running stress tests (split)." << std::endl;
+  testRandomSplit();
   std::cout << "Tests are finished. Passed " << total_checks << " checks." << std::endl;
 }
