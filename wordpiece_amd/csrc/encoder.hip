@@ -188,16 +188,24 @@ struct wp_vocab {
 
 namespace wp {
 
+static void free_vocab_tables(Context *c) {
+  for (void **p : {reinterpret_cast<void **>(&c->d_stream), reinterpret_cast<void **>(&c->d_elig_start),
+                   reinterpret_cast<void **>(&c->d_elig_info), reinterpret_cast<void **>(&c->d_soft),
+                   reinterpret_cast<void **>(&c->d_elig_id), reinterpret_cast<void **>(&c->d_tok_len),
+                   reinterpret_cast<void **>(&c->d_trie_key), reinterpret_cast<void **>(&c->d_trie_child),
+                   reinterpret_cast<void **>(&c->d_trie_id)}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+}
+
 static void destroy_context(Context *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (void *p : {static_cast<void *>(c->d_stream), static_cast<void *>(c->d_elig_start),
-                  static_cast<void *>(c->d_elig_info), static_cast<void *>(c->d_soft),
-                  static_cast<void *>(c->d_elig_id), static_cast<void *>(c->d_tok_len),
-                  static_cast<void *>(c->d_used), static_cast<void *>(c->d_lut), static_cast<void *>(c->d_scan_tmp),
+  free_vocab_tables(c);
+  for (void *p : {static_cast<void *>(c->d_used), static_cast<void *>(c->d_lut), static_cast<void *>(c->d_scan_tmp),
                   static_cast<void *>(c->d_scalars), static_cast<void *>(c->d_code),
-                  static_cast<void *>(c->d_symhist), static_cast<void *>(c->d_trie_key),
-                  static_cast<void *>(c->d_trie_child), static_cast<void *>(c->d_trie_id)}) {
+                  static_cast<void *>(c->d_symhist)}) {
     if (p) (void)hipFree(p);
   }
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
@@ -223,24 +231,44 @@ static T *upload(const std::vector<T> &v, hipStream_t st) {
   return d;
 }
 
-// a fresh context (streams, vocab tables, scratch) on `device` (< 0: the calling thread's current device)
-static std::unique_ptr<Context> make_context(const wp_vocab *v, int device) {
-  int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
-    throw HipError("no HIP device available: the Linear WordPiece path has no CPU fallback");
+// The reference's API has no handles: every word_piece::linear::encode(text, vocab) parses the vocabulary and
+// sets everything up again (linear.cpp:332-341), and its test-suite does that tens of thousands of times.
+// Here a context (two streams, events, code point tables, scalars, the arenas) costs ~1.5 ms to make, so
+// the contexts of destroyed handles are parked in a small process-wide pool and the next handle on the
+// same device takes one over, replacing only the vocabulary tables.  Arenas above kPoolArenaBytes are
+// given back to the driver first (a parked context must not sit on 100 GB of HBM).
+static constexpr size_t kPoolArenaBytes = size_t(16) << 30;
+static constexpr size_t kPoolContexts = 4;
+static std::mutex g_pool_mu;
+static std::vector<std::unique_ptr<Context>> &context_pool() {
+  static auto *pool = new std::vector<std::unique_ptr<Context>>();  // never destroyed: the HIP runtime may be gone by then
+  return *pool;
+}
+
+static void park_context(std::unique_ptr<Context> c) {
+  if (!c) return;
+  static const bool no_pool = getenv("WP_NO_CONTEXT_POOL") && atoi(getenv("WP_NO_CONTEXT_POOL")) != 0;
+  (void)hipSetDevice(c->device);
+  if (!no_pool && hipStreamSynchronize(c->stream) == hipSuccess && hipStreamSynchronize(c->stream2) == hipSuccess) {
+    free_vocab_tables(c.get());
+    if (c->text_buf.cap + c->a_buf.cap + c->b_buf.cap + c->fmt_buf.cap > kPoolArenaBytes) {
+      c->text_buf.release();
+      c->a_buf.release();
+      c->b_buf.release();
+      c->fmt_buf.release();
+    }
+    c->d_ids = nullptr;
+    c->dbg = {};
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    if (context_pool().size() < kPoolContexts) {
+      context_pool().push_back(std::move(c));
+      return;
+    }
   }
-  std::unique_ptr<Context> c(new Context());
-  if (device >= 0) {
-    if (device >= count) throw std::invalid_argument("no such HIP device: " + std::to_string(device));
-    c->device = device;
-  } else {
-    WP_HIP(hipGetDevice(&c->device));
-  }
-  WP_HIP(hipSetDevice(c->device));
-  WP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  WP_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-  for (auto &e : c->evs) WP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  const HostVocab &hv = v->hv;
+  destroy_context(c.get());
+}
+
+static void upload_vocab_tables(Context *c, const HostVocab &hv) {
   c->d_stream = upload(hv.stream, c->stream);
   c->d_elig_start = upload(hv.elig_start, c->stream);
   c->d_elig_info = upload(hv.elig_info, c->stream);
@@ -254,6 +282,48 @@ static std::unique_ptr<Context> make_context(const wp_vocab *v, int device) {
   }
   c->d_trie_child = upload(hv.trie_child, c->stream);
   c->d_trie_id = upload(hv.trie_id, c->stream);
+  WP_HIP(hipStreamSynchronize(c->stream));
+}
+
+// a context (streams, vocab tables, scratch) on `device` (< 0: the calling thread's current device): a parked
+// one if there is any, else a fresh one
+static std::unique_ptr<Context> make_context(const wp_vocab *v, int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+    throw HipError("no HIP device available: the Linear WordPiece path has no CPU fallback");
+  }
+  if (device >= 0) {
+    if (device >= count) throw std::invalid_argument("no such HIP device: " + std::to_string(device));
+  } else {
+    WP_HIP(hipGetDevice(&device));
+  }
+  WP_HIP(hipSetDevice(device));
+  std::unique_ptr<Context> c;
+  {
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    auto &pool = context_pool();
+    for (size_t i = 0; i < pool.size(); i++) {
+      if (pool[i]->device == device) {
+        c = std::move(pool[i]);
+        pool.erase(pool.begin() + static_cast<long>(i));
+        break;
+      }
+    }
+  }
+  if (c) {
+    try {
+      upload_vocab_tables(c.get(), v->hv);
+    } catch (...) {
+      destroy_context(c.get());
+      throw;
+    }
+    return c;
+  }
+  c.reset(new Context());
+  c->device = device;
+  WP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  WP_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  for (auto &e : c->evs) WP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   WP_HIP(hipMalloc(&c->d_used, sizeof(uint32_t) * kCpTableSize));
   WP_HIP(hipMalloc(&c->d_lut, sizeof(uint32_t) * kCpTableSize));
   WP_HIP(hipMalloc(&c->d_scan_tmp, sizeof(uint32_t) * (cdiv(kCpTableSize, kScanTile) + 8)));
@@ -262,7 +332,7 @@ static std::unique_ptr<Context> make_context(const wp_vocab *v, int device) {
   WP_HIP(hipMalloc(&c->d_symhist, sizeof(uint32_t) * 256));
   WP_HIP(hipHostMalloc(&c->h_scalars, sizeof(uint32_t) * kScalars));
   for (auto &e : c->ev) WP_HIP(hipEventCreate(&e));
-  WP_HIP(hipStreamSynchronize(c->stream));
+  upload_vocab_tables(c.get(), v->hv);
   return c;
 }
 
@@ -1203,8 +1273,8 @@ static void encode_fast_on_device(const wp_vocab *v, Context *c, const uint8_t *
 }  // namespace wp
 
 wp_vocab::~wp_vocab() {
-  destroy_context(ctx.get());
-  for (auto &c : multi) destroy_context(c.get());
+  park_context(std::move(ctx));
+  for (auto &c : multi) park_context(std::move(c));
 }
 
 // ======================================================================================
@@ -1461,7 +1531,7 @@ void encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const std::vecto
   if (v->multi.size() < static_cast<size_t>(G)) v->multi.resize(static_cast<size_t>(G));
   for (int g = 0; g < G; g++) {  // (contexts are made on the calling thread: a failure here is a plain exception)
     Context *c = v->multi[static_cast<size_t>(g)].get();
-    if (c && c->device != devices[static_cast<size_t>(g)]) v->multi[static_cast<size_t>(g)].reset();
+    if (c && c->device != devices[static_cast<size_t>(g)]) park_context(std::move(v->multi[static_cast<size_t>(g)]));
     if (!v->multi[static_cast<size_t>(g)]) v->multi[static_cast<size_t>(g)] = make_context(v, devices[static_cast<size_t>(g)]);
   }
   const std::vector<size_t> cuts = shard_cuts(utf8, nbytes, G);

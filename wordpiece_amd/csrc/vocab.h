@@ -4,7 +4,6 @@
 #include <algorithm>
 #include <cstdint>
 #include <iostream>
-#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -157,7 +156,6 @@ struct HostVocab {
     n_dup_eligible = 0;
     low_cp = false;
     space_in_token = false;
-    std::map<std::pair<bool, std::vector<uint32_t>>, int> seen;
     std::vector<uint32_t> starts(tokens.size());
     std::vector<size_t> elig;
     for (size_t i = 0; i < tokens.size(); i++) {
@@ -170,7 +168,6 @@ struct HostVocab {
       }
       if (!t.is_special && !t.is_malformed) {  // linear.cpp:179
         elig.push_back(i);
-        if (++seen[{t.is_prefix, t.word}] > 1) n_dup_eligible++;
         if (t.word.size() > 1) {
           for (uint32_t c : t.word) {
             if (is_spacing_char(c)) soft.push_back(c);
@@ -183,7 +180,29 @@ struct HostVocab {
     }
     // eligible tokens in lexicographic order of their words (a proper prefix first): the order of their
     // suffixes in S, so that the marks of the text-only layout come out sorted by slot
-    std::stable_sort(elig.begin(), elig.end(), [&](size_t a, size_t b) { return tokens[a].word < tokens[b].word; });
+    // (the first three code points packed into one integer decide most comparisons without touching the vectors)
+    std::vector<std::pair<uint64_t, size_t>> order(elig.size());
+    for (size_t k = 0; k < elig.size(); k++) {
+      const std::vector<uint32_t> &w = tokens[elig[k]].word;
+      uint64_t key = 0;
+      for (size_t j = 0; j < 3; j++) key = (key << 21) | (j < w.size() ? static_cast<uint64_t>(w[j]) + 1 : 0);
+      order[k] = {key, elig[k]};
+    }
+    std::stable_sort(order.begin(), order.end(), [&](const std::pair<uint64_t, size_t> &a, const std::pair<uint64_t, size_t> &b) {
+      if (a.first != b.first) return a.first < b.first;
+      return tokens[a.second].word < tokens[b.second].word;
+    });
+    for (size_t k = 0; k < elig.size(); k++) elig[k] = order[k].second;
+    // same-class duplicates (they force the true suffix array): equal words are adjacent now
+    for (size_t a = 0; a < elig.size();) {
+      size_t b = a, np = 0, ns = 0;
+      while (b < elig.size() && tokens[elig[b]].word == tokens[elig[a]].word) {
+        (tokens[elig[b]].is_prefix ? np : ns)++;
+        b++;
+      }
+      n_dup_eligible += static_cast<int64_t>((np > 1 ? np - 1 : 0) + (ns > 1 ? ns - 1 : 0));
+      a = b;
+    }
     for (size_t i : elig) {
       const HostToken &t = tokens[i];
       elig_start.push_back(starts[i]);
