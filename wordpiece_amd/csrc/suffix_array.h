@@ -487,8 +487,14 @@ __global__ __launch_bounds__(kBlock) void widen_keys_kernel(const Key0 *__restri
 // The one dependency across tiles — where does the group that reaches into this wave's first entry
 // start — is answered by the keys themselves: a look at the 64 entries in front of the wave, and a
 // binary search in the sorted keys for the rare group that is longer than that.
-constexpr int kR0Rounds = 16;  // 1024 entries per wave: the look behind the wave is paid once per 1024 entries
-constexpr int kR0Tile = kBlock * kR0Rounds;
+// Layout: a lane owns kR0Vec consecutive entries per step (16-byte loads and stores of keys, ranks and
+// LCPs; the 4-byte-per-lane form of the same kernel ran at 2.3 TB/s), a wave kR0Steps steps of 64 x kR0Vec
+// entries; neighbours across lanes come by shuffles, the head carried across lanes by one ballot + one
+// variable-lane shuffle.  lcp[k] (boundary between slots k and k+1) is written by the owner of slot k.
+constexpr int kR0Vec = 16 / static_cast<int>(sizeof(Key0)) * 2;  // 8 entries (u32 keys: 2 x uint4) or 4 (u64 keys: 2 x 16 B)
+constexpr int kR0Steps = 2;
+constexpr int kR0WaveSpan = kWave * kR0Vec * kR0Steps;
+constexpr int kR0Tile = (kBlock / kWave) * kR0WaveSpan;
 __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restrict__ keys,
                                                              const uint32_t *__restrict__ vals, size_t n,
                                                              const uint8_t *__restrict__ first_len, int uniform_bits,
@@ -496,20 +502,29 @@ __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restr
                                                              int32_t *__restrict__ lcp, uint32_t *__restrict__ gdepth) {
   __shared__ uint8_t s_fl[kDecodeTableBytes];
   const int lane = lane_id(), w = wave_id();
-  const size_t wave_base = static_cast<size_t>(blockIdx.x) * kR0Tile + static_cast<size_t>(w) * (kWave * kR0Rounds);
-  // all loads of the wave are issued before anything waits: a lane's key in every round (the neighbours'
-  // keys come by lane shuffles, the two at the round edges from the 65th / 0th load), and the 64 keys in
-  // front of the wave for the carried head
-  uint64_t me[kR0Rounds];
+  const size_t wave_base = static_cast<size_t>(blockIdx.x) * kR0Tile + static_cast<size_t>(w) * kR0WaveSpan;
+  // all loads of the wave are issued before anything waits (~0 is never a key: registers hold 64 bits)
+  uint64_t me[kR0Steps][kR0Vec];
 #pragma unroll
-  for (int r = 0; r < kR0Rounds; r++) {
-    const size_t k = wave_base + static_cast<size_t>(r) * kWave + lane;
-    me[r] = k < n ? static_cast<uint64_t>(keys[k]) : ~0ull;  // (registers hold 64 bits: ~0 is never a key)
+  for (int t = 0; t < kR0Steps; t++) {
+    const size_t k0 = wave_base + (static_cast<size_t>(t) * kWave + lane) * kR0Vec;
+    if (k0 + kR0Vec <= n) {  // (the key buffer is 256-byte aligned and k0 a multiple of kR0Vec: aligned 16-byte loads)
+      Key0 tmp[kR0Vec];
+      const uint4 *src = reinterpret_cast<const uint4 *>(keys + k0);
+      uint4 a = src[0], b = src[1];
+      __builtin_memcpy(tmp, &a, 16);
+      __builtin_memcpy(reinterpret_cast<char *>(tmp) + 16, &b, 16);
+#pragma unroll
+      for (int j = 0; j < kR0Vec; j++) me[t][j] = static_cast<uint64_t>(tmp[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kR0Vec; j++) me[t][j] = k0 + j < n ? static_cast<uint64_t>(keys[k0 + j]) : ~0ull;
+    }
   }
   const bool have_front = wave_base < n && wave_base >= 1 + static_cast<size_t>(lane);
   const uint64_t front = have_front ? static_cast<uint64_t>(keys[wave_base - 1 - lane]) : ~0ull;  // lane l: the key l + 1 entries in front
-  const size_t after_idx = wave_base + static_cast<size_t>(kWave) * kR0Rounds;
-  const uint64_t after = after_idx < n ? static_cast<uint64_t>(keys[after_idx]) : ~0ull;  // (wave-uniform address: one broadcast load)
+  const size_t after_idx = wave_base + kR0WaveSpan;
+  const uint64_t after = after_idx < n ? static_cast<uint64_t>(keys[after_idx]) : ~0ull;  // (one broadcast load)
   if (uniform_bits <= 0) {
     for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
       reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
@@ -519,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restr
   if (wave_base >= n) return;
   size_t carry = wave_base;  // head of the group of the entries in front of the first head seen by this wave
   {
-    const uint64_t me0 = __shfl(me[0], 0, kWave);
+    const uint64_t me0 = __shfl(me[0][0], 0, kWave);
     const uint64_t neq = ~__ballot(have_front && front == me0);
     if (neq & 1ull) {
       carry = wave_base;  // the entry in front has another key (or there is none): the wave starts a group
@@ -529,41 +544,83 @@ __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restr
       size_t lo = 0, hi = wave_base - kWave;
       while (lo < hi) {
         const size_t md = (lo + hi) >> 1;
-        if (keys[md] < me0) lo = md + 1; else hi = md;
+        if (static_cast<uint64_t>(keys[md]) < me0) lo = md + 1; else hi = md;
       }
       carry = lo;
     }
   }
-  uint64_t prev_last = __shfl(front, 0, kWave);  // key of the entry in front of the current round
+  uint64_t prev_last = __shfl(front, 0, kWave);  // key of the entry in front of the current step
 #pragma unroll
-  for (int r = 0; r < kR0Rounds; r++) {
-    const size_t round_base = wave_base + static_cast<size_t>(r) * kWave;
-    const size_t k = round_base + lane;
-    const bool valid = k < n;
-    const uint64_t up = __shfl_up(me[r], 1, kWave), dn = __shfl_down(me[r], 1, kWave);
-    const uint64_t next_first = r + 1 < kR0Rounds ? __shfl(me[r + 1 < kR0Rounds ? r + 1 : r], 0, kWave) : after;
-    const uint64_t prev = lane == 0 ? prev_last : up;
-    const uint64_t next = lane == kWave - 1 ? next_first : dn;
-    // (k == 0: prev_last is ~0, never a key; past the end: ~0 as well, so the last entry sees another key)
-    const bool f = valid && prev != me[r];
-    const bool sg = f && next != me[r];
-    const uint64_t bf = __ballot(f);
-    if (valid) {
-      const uint64_t mine = bf & (((1ull << lane) - 1ull) | (1ull << lane));
-      const size_t head = mine ? round_base + static_cast<size_t>(63 - __clzll(static_cast<long long>(mine))) : carry;
-      hd[k] = static_cast<RankEntry>(head);
-      if (sa_dbg) sa_dbg[k] = vals[k];
-      if (k > 0) {
-        int32_t l = -1;
-        if (f) {
-          l = count_key_symbols(me[r], __clzll(static_cast<long long>(me[r] ^ prev)) - (64 - kKeyBits), s_fl, uniform_bits);
-        }
-        lcp[k - 1] = l;
-      }
-      if (f && !sg) gdepth[k] = static_cast<uint32_t>(count_key_symbols(me[r], kKeyBits, s_fl, uniform_bits));
+  for (int t = 0; t < kR0Steps; t++) {
+    const size_t k0 = wave_base + (static_cast<size_t>(t) * kWave + lane) * kR0Vec;
+    const uint64_t up = __shfl_up(me[t][kR0Vec - 1], 1, kWave), dn = __shfl_down(me[t][0], 1, kWave);
+    const uint64_t next_first = t + 1 < kR0Steps ? __shfl(me[t + 1 < kR0Steps ? t + 1 : t][0], 0, kWave) : after;
+    const uint64_t prevk = lane == 0 ? prev_last : up;
+    const uint64_t nextk = lane == kWave - 1 ? next_first : dn;
+    // flags of the lane's entries; the last head inside the lane
+    bool f[kR0Vec];
+    int last = -1;
+#pragma unroll
+    for (int j = 0; j < kR0Vec; j++) {
+      const uint64_t p = j == 0 ? prevk : me[t][j - 1];
+      f[j] = k0 + j < n && p != me[t][j];
+      if (f[j]) last = j;
     }
-    if (bf) carry = round_base + static_cast<size_t>(63 - __clzll(static_cast<long long>(bf)));
-    prev_last = __shfl(me[r], kWave - 1, kWave);
+    // head carried into the lane: the last head of the nearest lower lane that has one, else the wave's carry
+    const uint64_t bh = __ballot(last >= 0);
+    const uint64_t lower = bh & ((1ull << lane) - 1ull);
+    const int src_lane = lower ? 63 - __clzll(static_cast<long long>(lower)) : 0;
+    const uint32_t my_last_pos = static_cast<uint32_t>(k0 + (last >= 0 ? last : 0));
+    const uint32_t from_lane = __shfl(my_last_pos, src_lane, kWave);
+    size_t head = lower ? static_cast<size_t>(from_lane) : carry;
+    uint32_t hv[kR0Vec];
+    int32_t lv[kR0Vec];
+#pragma unroll
+    for (int j = 0; j < kR0Vec; j++) {
+      if (f[j]) head = k0 + j;
+      hv[j] = static_cast<uint32_t>(head);
+      // boundary between slot k0 + j and the next one
+      const uint64_t nx = j + 1 < kR0Vec ? me[t][j + 1 < kR0Vec ? j + 1 : j] : nextk;
+      int32_t l = -1;
+      if (k0 + j + 1 < n && nx != me[t][j]) {
+        l = count_key_symbols(nx, __clzll(static_cast<long long>(nx ^ me[t][j])) - (64 - kKeyBits), s_fl, uniform_bits);
+      }
+      lv[j] = l;
+      if (f[j]) {  // head of a tied group (the next entry has the same key): its depth
+        if (k0 + j + 1 < n && nx == me[t][j]) {
+          gdepth[k0 + j] = static_cast<uint32_t>(count_key_symbols(me[t][j], kKeyBits, s_fl, uniform_bits));
+        }
+      }
+    }
+    if (k0 + kR0Vec <= n) {
+      uint4 *hdst = reinterpret_cast<uint4 *>(hd + k0), *ldst = reinterpret_cast<uint4 *>(lcp + k0);
+#pragma unroll
+      for (int q = 0; q < kR0Vec / 4; q++) {
+        hdst[q] = make_uint4(hv[4 * q], hv[4 * q + 1], hv[4 * q + 2], hv[4 * q + 3]);
+        ldst[q] = make_uint4(static_cast<uint32_t>(lv[4 * q]), static_cast<uint32_t>(lv[4 * q + 1]),
+                             static_cast<uint32_t>(lv[4 * q + 2]), static_cast<uint32_t>(lv[4 * q + 3]));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kR0Vec; j++) {
+        if (k0 + j < n) {
+          hd[k0 + j] = hv[j];
+          if (k0 + j + 1 < n) lcp[k0 + j] = lv[j];
+        }
+      }
+    }
+    if (sa_dbg) {
+#pragma unroll
+      for (int j = 0; j < kR0Vec; j++) {
+        if (k0 + j < n) sa_dbg[k0 + j] = vals[k0 + j];
+      }
+    }
+    // wave carry for the next step: the last head of the highest lane that has one
+    if (bh) {
+      const int hl = 63 - __clzll(static_cast<long long>(bh));
+      carry = static_cast<size_t>(__shfl(my_last_pos, hl, kWave));
+    }
+    prev_last = __shfl(me[t][kR0Vec - 1], kWave - 1, kWave);
   }
 }
 
