@@ -1,25 +1,21 @@
-"""Prints the kernel timeline of the last encode in a rocprofv3 kernel trace CSV (one line per launch:
-start offset us, duration us, gap to the previous launch on the same stream, stream, kernel, workgroups)."""
+"""Timeline of the last Linear step of a rocprofv3 kernel trace: start (us), duration (us), queue, kernel, grid.
+
+python profiles/timeline.py gpurun_out/<dir>/<name>_kernel_trace.csv [min_us]"""
 import csv
-import glob
 import sys
 
-f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[0]
-rows = list(csv.DictReader(open(f)))
+rows = list(csv.DictReader(open(sys.argv[1])))
+min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "decode_count" in r["Kernel_Name"]]
-s = idx[-1]
+starts = [i for i, r in enumerate(rows) if "decode_count" in r["Kernel_Name"]]
+ranks = [i for i, r in enumerate(rows) if "round0_rank" in r["Kernel_Name"]]
+last = ranks[-1]
+s = max(i for i in starts if i < last)
+e = min([i for i in starts if i > last] + [len(rows)])
 t0 = int(rows[s]["Start_Timestamp"])
-prev_end = {}
-for r in rows[s:]:
-    st = int(r["Start_Timestamp"]) - t0
-    en = int(r["End_Timestamp"]) - t0
-    q = r["Stream_Id"]
-    gap = st - prev_end.get(q, 0)
-    name = r["Kernel_Name"].replace("void ", "").replace("wp::", "")[:38]
-    if en - st < 12000 and len(sys.argv) > 2:
-        prev_end[q] = en
+for r in rows[s:e]:
+    k = r["Kernel_Name"].replace("void wp::", "").replace("wp::", "").split("(")[0][:48]
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    if d < min_us:
         continue
-    print("%9.1f %8.1f gap%7.1f s%s %s g=%d" % (st / 1e3, (en - st) / 1e3, gap / 1e3, q, name,
-                                               int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])))
-    prev_end[q] = en
+    print("%8.1f %8.1f  q%-3s %-48s grid %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, d, r["Queue_Id"], k, r["Grid_Size_X"]))

@@ -509,8 +509,8 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   const unsigned sl_groups = cdiv(sl_tiles, kSlGroup);
   for (int pass = 0; pass < 2; pass++) {
     d_sym = ar.take<SymT>(n + 16);
-    K0 = ar.take<uint64_t>(n);
-    K1 = ar.take<uint64_t>(n);
+    K0 = ar.take<uint64_t>(n + 2);  // (+2: the rank store's scratch list starts at a multiple of 4 entries behind hd)
+    K1 = ar.take<uint64_t>(n + 2);
     DG0 = use_digit_bytes ? ar.take<uint8_t>(n + 64) : nullptr;
     DG1 = use_digit_bytes ? ar.take<uint8_t>(n + 64) : nullptr;
     d_claim = ar.take<uint32_t>(claim_size);
@@ -660,24 +660,69 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     if (bin_bits > 0 && m >= (1u << 22)) {
       const int hb = bit_length(n - 1);
       // (the top bits of a text position are uniformly distributed: histogram by LDS atomics)
-      // (with 32-bit round-0 keys this is the same kernel as the passes of the suffix sort — 8-byte records —
-      // and its full-size launch is part of the same roofline statistics)
       const int bc = radix_sort_pairs<uint32_t>(dst, val, t_dst, t_val, m, std::max(0, hb - bin_bits), hb, d_radix_tmp,
-                                                radix_words, st, (sizeof(Key0) == 4 && m == n) ? &c->rstats : nullptr, false,
-                                                hb + 1);
+                                                radix_words, st, nullptr, false, hb + 1);
       hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, bc ? t_dst : dst,
                          bc ? t_val : val, m, d_rank, n, 1);
     } else {
       hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, dst, val, m, d_rank, n, 0);
     }
   };
+  // Round 0 stores a rank for every position: a permutation.  The list is partitioned by ALL destination bits
+  // above kWinBits (one or two radix passes over 8-byte records; their histograms read the digit bytes the
+  // pass before left behind) and every 2^kWinBits-slot window of the rank table is then assembled in LDS and
+  // written with full-width stores (window_store_kernel).  The passes go through scratch pairs (a: behind hd and
+  // the sorted keys, which nobody reads after this; b: large-group buffers, idle in round 0) because vals and
+  // hd are still needed.  dig: digit bytes of dst bits [kWinBits, kWinBits + 8), other: the second byte buffer.
+  static const bool env_old_store = env_flag("WP_RANK_STORE_SCATTER");
+  const int hb_n = bit_length(n - 1);
+  const bool window_store = !env_old_store && bin_bits > 0 && n >= (1u << 22) && sizeof(Key0) == 4;
+  // (more than 8 bits above the window: two passes of about half the bits each — 2^6 bins instead of 2^8 and
+  // 2^4 for 1e8 positions: with uniform digits the runs a tile appends to its bins are 4096 / bins entries, and
+  // 16-entry runs leave the workgroup as half lines: 0.51 ms for that pass against 0.34 ms)
+  const int win_mid = hb_n - kWinBits <= kRadixBits ? hb_n : kWinBits + (hb_n - kWinBits + 1) / 2;
+  auto store_ranks_round0 = [&](uint32_t *dst, uint32_t *val, uint32_t *a_dst, uint32_t *a_val, uint32_t *b_dst,
+                                uint32_t *b_val, uint8_t *dig, uint8_t *other) {
+    // (a per-device attribute: set on every call, the context may live on any device)
+    WP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(window_store_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kWinLdsBytes)));
+    const int mid = win_mid;
+    DigitBytes d1;
+    d1.dg0 = dig;
+    d1.dg1 = other;
+    d1.dg0_ready = dig != nullptr;
+    if (mid < hb_n) {  // (the first pass leaves the second pass's digits)
+      d1.tail_bit = mid;
+      d1.tail_mask = (1u << (hb_n - mid)) - 1u;
+    }
+    radix_sort_pairs<uint32_t>(dst, val, a_dst, a_val, n, kWinBits, mid, d_radix_tmp, radix_words, st, &c->rstats, false,
+                               hb_n + 1, d1);
+    const uint32_t *f_dst = a_dst, *f_val = a_val;
+    if (mid < hb_n) {
+      DigitBytes d2;
+      d2.dg0 = dig ? d1.tail_out(1) : nullptr;
+      d2.dg1 = dig ? dig : nullptr;
+      d2.dg0_ready = dig != nullptr;
+      radix_sort_pairs<uint32_t>(a_dst, a_val, b_dst, b_val, n, mid, hb_n, d_radix_tmp, radix_words, st, &c->rstats,
+                                 false, hb_n + 1, d2);
+      f_dst = b_dst;
+      f_val = b_val;
+    }
+    hipLaunchKernelGGL(window_store_kernel, dim3(cdiv(n, size_t(1) << kWinBits)), dim3(kWinThreads), kWinLdsBytes, st, f_dst,
+                       f_val, n, d_rank);
+  };
   // (the low bits of a round-0 key are the tail of a compressed codeword stream: near-uniform digits)
   DigitBytes db;
   db.dg0 = DG0;
   db.dg1 = DG1;
   db.dg0_ready = DG0 != nullptr;
+  if (window_store) {  // the last pass leaves the first digit of the rank store's destination partition
+    db.tail_bit = kWinBits;
+    db.tail_mask = (1u << (win_mid - kWinBits)) - 1u;
+    db.tail_from_val = true;
+  }
   // histogram by LDS atomics for the digits below this bit (near-uniform digits), by match-any ballots above
-  static const int hist_atomic_bits = getenv("WP_HIST_ATOMIC_BITS") ? atoi(getenv("WP_HIST_ATOMIC_BITS")) : 16;
+  static const int hist_atomic_bits = getenv("WP_HIST_ATOMIC_BITS") ? atoi(getenv("WP_HIST_ATOMIC_BITS")) : 8;
   // (round-0 keys of up to 32 bits live as uint32 in the first half of the 64-bit key buffers)
   // (round-0 keys of up to 32 bits live as uint32 in the first half of the 64-bit key buffers)
   int cur = radix_sort_pairs<Key0>(reinterpret_cast<Key0 *>(K0), V0, reinterpret_cast<Key0 *>(K1), V1, n, 0, kKeyBits,
@@ -752,7 +797,13 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
                          slots, other_vals, AG, adep, d_ghead, d_gdepth, c->d_scalars + 4);
     }
     fork();
-    store_ranks(vals, hd, reinterpret_cast<uint32_t *>(hd) + n, reinterpret_cast<uint32_t *>(keys), n);
+    if (window_store) {
+      store_ranks_round0(vals, hd, reinterpret_cast<uint32_t *>(hd) + ((n + 3) & ~static_cast<size_t>(3)),
+                         reinterpret_cast<uint32_t *>(keys), LV0, LV1, DG0 ? db.tail_out(cur) : nullptr,
+                         DG0 ? db.tail_out(cur ^ 1) : nullptr);
+    } else {
+      store_ranks(vals, hd, reinterpret_cast<uint32_t *>(hd) + n, reinterpret_cast<uint32_t *>(keys), n);
+    }
     WP_LAUNCH_CHECK();
     classified = classify_groups(n);
     join();

@@ -98,9 +98,16 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
   // no LDS atomics, no same-address serialisation on skewed digits.  lds_atomics: one LDS atomic per
   // key instead — faster when the digit is close to uniform (the two lowest digits of the round-0
   // keys: 0.18-0.19 vs 0.21-0.22 ms), slower on the skewed high digits (0.23 vs 0.21 ms).
-  __shared__ uint32_t sh[WAVES][kRadixBins];
+  // lds_atomics == 2: one LDS atomic per key into one of kHistCopies interleaved copies of the histogram
+  // (copy = lane % kHistCopies, counter of digit d in copy c at d * kHistCopies + c: the lanes of a wave that
+  // share a digit spread over kHistCopies addresses in kHistCopies different banks) — for skewed digits, where
+  // a fifth of a wave's lanes can hold the same digit.
+  constexpr int kHistCopies = 8;
+  static_assert(kHistCopies >= WAVES, "the per-wave modes use the first WAVES rows");
+  __shared__ uint32_t sh[kHistCopies][kRadixBins];
+  uint32_t *flat = &sh[0][0];
 #pragma unroll
-  for (int i = 0; i < WAVES; i++) {
+  for (int i = 0; i < kHistCopies; i++) {
 #pragma unroll
     for (int q = 0; q < kBinsPerThread; q++) sh[i][q * kBlock + threadIdx.x] = 0;
   }
@@ -138,7 +145,11 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
 #if defined(WP_HIST_NOCOUNT)  // probe only (profiles/tools/hist_probe.hip): loads without counting
     if (i < n && d == 0x1ffu) sh[w][0] = 1;
 #else
-    if (lds_atomics) {  // wave-uniform
+    if (lds_atomics == 2) {  // (kernel argument: wave-uniform)
+      if (i < n) atomicAdd(&flat[d * kHistCopies + (lane & (kHistCopies - 1))], 1u);
+      continue;
+    }
+    if (lds_atomics) {
       if (i < n) atomicAdd(&sh[w][d], 1u);
       continue;
     }
@@ -156,8 +167,13 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
   for (int q = 0; q < kBinsPerThread; q++) {
     const int d = q * kBlock + threadIdx.x;
     uint32_t c = 0;
+    if (lds_atomics == 2) {
 #pragma unroll
-    for (int i = 0; i < WAVES; i++) c += sh[i][d];
+      for (int i = 0; i < kHistCopies; i++) c += flat[d * kHistCopies + i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < WAVES; i++) c += sh[i][d];
+    }
     table[static_cast<size_t>(blockIdx.x) * kRadixBins + d] = c;
     if (c) atomicAdd(&chunk_sums[static_cast<size_t>(blockIdx.x / kColChunk) * kRadixBins + d], c);
   }
@@ -279,10 +295,11 @@ template <typename KeyT, int ITEMS>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
     uint32_t *__restrict__ vout, size_t n, int begin_bit, uint32_t mask,
-    const uint32_t *__restrict__ goff, uint8_t *__restrict__ dout, int next_bit, uint32_t next_mask) {
+    const uint32_t *__restrict__ goff, uint8_t *__restrict__ dout, int next_bit, uint32_t next_mask, int dig_from_val) {
   // dout != nullptr: also leave the next pass's digit of every key as one byte at its new position,
   // so that the next histogram reads 1 byte per key instead of the key (a pass is the
-  // 12-byte record read and written; this adds 1 + 1)
+  // 12-byte record read and written; this adds 1 + 1).  dig_from_val: the digit is taken from the
+  // value (the sort that follows is keyed by the values: the destination partition of the rank store).
   constexpr int TILE = kBlock * ITEMS;
   constexpr int WAVES = kBlock / kWave;
   __shared__ uint32_t wcnt[WAVES][kRadixBins];
@@ -367,9 +384,10 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
       const uint32_t d = static_cast<uint32_t>(kk >> begin_bit) & mask;
       const size_t o = static_cast<size_t>(gbase[d]) + k;
       if (!wp_in_bounds(o < n, kSiteRadixScatter)) continue;
+      const uint32_t vv = svals[k];
       kout[o] = kk;
-      vout[o] = svals[k];
-      if (dout) dout[o] = static_cast<uint8_t>(static_cast<uint32_t>(kk >> next_bit) & next_mask);
+      vout[o] = vv;
+      if (dout) dout[o] = static_cast<uint8_t>((dig_from_val ? vv >> next_bit : static_cast<uint32_t>(kk >> next_bit)) & next_mask);
     }
   }
 }
@@ -441,9 +459,21 @@ struct BitRange {
 // uniform_low_bits: digits below this bit are close to uniformly distributed (histogram by LDS atomics)
 // dg0/dg1 (optional, n + 64 bytes each, pairs with k0/k1): digit bytes — every scatter leaves the next
 // pass's digits there; dg0_ready: dg0 already holds the first pass's digits (written by the key builder)
+// histogram of a digit that is not known to be uniform: 2 = interleaved copies + LDS atomics, 0 = match-any ballots
+inline int hist_skew_mode() {
+  static const int m = getenv("WP_HIST_SKEW") ? atoi(getenv("WP_HIST_SKEW")) : 2;
+  return m;
+}
+
 struct DigitBytes {
   uint8_t *dg0 = nullptr, *dg1 = nullptr;
   bool dg0_ready = false;
+  // tail: the LAST pass also leaves digit bytes, for a sort that follows this one — bits [tail_bit, ...) & tail_mask
+  // of the key, or of the value (tail_from_val).  They end up in tail_out(returned cur).
+  int tail_bit = -1;
+  uint32_t tail_mask = 0;
+  bool tail_from_val = false;
+  uint8_t *tail_out(int cur) const { return cur ? dg1 : dg0; }
 };
 
 template <typename KeyT>
@@ -488,15 +518,17 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
     // digit bytes: read where the previous pass (or the key builder) left them, written for the next pass
     const uint8_t *dgi = nullptr;
     if (db.dg0 && (pi > 0 || db.dg0_ready)) dgi = cur ? db.dg1 : db.dg0;
-    uint8_t *dgo = (db.dg0 && pi + 1 < passes.size()) ? (cur ? db.dg0 : db.dg1) : nullptr;
-    const int nbit = pi + 1 < passes.size() ? passes[pi + 1].bit : 0;
-    const uint32_t nmask = pi + 1 < passes.size() ? passes[pi + 1].mask : 0u;
+    const bool last = pi + 1 == passes.size();
+    uint8_t *dgo = (db.dg0 && (!last || db.tail_bit >= 0)) ? (cur ? db.dg0 : db.dg1) : nullptr;
+    const int nbit = !last ? passes[pi + 1].bit : std::max(db.tail_bit, 0);
+    const uint32_t nmask = !last ? passes[pi + 1].mask : db.tail_mask;
+    const int from_val = last && db.tail_from_val ? 1 : 0;
     if (small) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT, RadixCfg<KeyT>::kSmallItems>), dim3(ntiles),
                          dim3(kBlock), 0, st, ki, dgi, n, b, mask, table, chunk_sums, 0);
     } else {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT, RadixCfg<KeyT>::kItems>), dim3(ntiles),
-                         dim3(kBlock), 0, st, ki, dgi, n, b, mask, table, chunk_sums, b < uniform_low_bits ? 1 : 0);
+                         dim3(kBlock), 0, st, ki, dgi, n, b, mask, table, chunk_sums, b < uniform_low_bits ? 1 : hist_skew_mode());
     }
     if (small && kRadixBins == kBlock) {
       hipLaunchKernelGGL(radix_apply_small_kernel, dim3(nchunks), dim3(kRadixBins), 0, st, table, chunk_sums, nchunks, ntiles);
@@ -508,10 +540,10 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
     const uint32_t *vsrc = identity_vals ? static_cast<const uint32_t *>(nullptr) : vi;
     if (small) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kSmallItems>), dim3(ntiles),
-                         dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask);
+                         dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
     } else {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems>), dim3(ntiles),
-                         dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask);
+                         dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
     }
     identity_vals = false;
     WP_LAUNCH_CHECK();
