@@ -142,6 +142,11 @@ int64_t wp_vocab_token_utf8(const wp_vocab *v, int64_t i, char *buf, size_t cap)
                                  the reference's layout is still used for the true suffix array (full
                                  depth, duplicate lines) and when text or tokens hold U+0000 / U+0001.
                                  Same token ids either way. */
+#define WP_OPT_SPARSE_EMIT 11 /* 1: the walk writes each id into a per-position array that is compacted
+                                 afterwards, always.  Default 0: that path is taken only when several
+                                 kernels contribute ids (words longer than a lane walks, coverage anchors);
+                                 otherwise every workgroup of the walk leaves one compact id list.
+                                 Same token ids either way (also env WP_SPARSE_EMIT=1). */
 int wp_set_option(wp_vocab *v, int option, int64_t value);
 
 /* ---- statistics of the last encode on this handle (for bench.py / roofline) ---- */
@@ -174,7 +179,7 @@ typedef struct {
                                  round 1 (-1: every tied group does, e.g. full depth)          */
   int32_t key_bits;           /* bits of the codeword stream in a round-0 key; keys of up to 32 bits
                                  are sorted as 8-byte (key, index) records, longer ones as 12-byte */
-  int32_t reserved1;
+  int32_t staged_emit;        /* 1: ids left the walk as per-workgroup lists (see WP_OPT_SPARSE_EMIT) */
 } wp_stats;
 int wp_get_stats(const wp_vocab *v, wp_stats *out);
 

@@ -495,3 +495,36 @@ def test_low_code_points_use_the_reference_layout():
     gv = W.Vocab(vocab)
     assert np.array_equal(gv.encode(b"ab a\x01 ab"), O.Vocab(vocab).encode(b"ab a\x01 ab"))
     assert gv.stats()["vocab_in_s"] == 1
+
+
+def test_staged_and_sparse_id_output_agree():
+    """The walk leaves its ids either as per-workgroup lists (default where one kernel produces all ids) or in
+    the per-position array compacted afterwards (WP_OPT_SPARSE_EMIT; long words; coverage anchors).  Same ids,
+    Linear and fast, against the oracle: words that fail after several tokens (roll-back), words of more than
+    kStageIds tokens (ids beyond the LDS stage), empty and all-blank inputs, long words (sparse by necessity)."""
+    rng = random.Random(99)
+    vocab = ["[UNK]", "a", "b", "##a", "##b", "ab", "##ab", "abab", "##c", "c", ",", "##abababab"]
+    texts = [b"", b"   ", b"a", b"ab" * 40 + b"d " + b"abc" * 9 + b" , c,ab", (b"ab" * 3 + b" ") * 3000 + b"abd " * 100]
+    for _ in range(40):
+        words = []
+        for _ in range(rng.randint(1, 400)):
+            words.append("".join(rng.choice("abcd,") for _ in range(rng.choice([1, 2, 3, 5, 9, 30]))))
+        texts.append(" ".join(words).encode())
+    texts.append(b"ab" * 5000 + b" a b " + b"ba" * 3000 + b"d")  # long words: pointer doubling, sparse output
+    big, big_vocab = synth.english_corpus(3_000_000, seed=77, vocab_size=8000)
+    cases = [(t, vocab) for t in texts] + [(big, big_vocab)]
+    for text, vc in cases:
+        ov = O.Vocab(vc)
+        exp = ov.encode(text, threads=8) if len(text) > 1_000_000 else ov.encode(text)
+        exp_fast = ov.fast_encode(text)
+        a, b = W.Vocab(vc), W.Vocab(vc)
+        b.set_option(W.WP_OPT_SPARSE_EMIT, 1)
+        ia, ib = a.encode(text), b.encode(text)
+        label = repr(text[:50])
+        assert np.array_equal(ia, exp) and np.array_equal(ib, exp), label
+        if len(text) and not text.isspace():
+            long_words = max(len(w) for w in text.split()) > 4000
+            assert a.stats()["staged_emit"] == (0 if long_words else 1), label
+            assert b.stats()["staged_emit"] == 0, label
+        fa, fb = a.fast_encode(text), b.fast_encode(text)
+        assert np.array_equal(fa, exp_fast) and np.array_equal(fb, exp_fast), label

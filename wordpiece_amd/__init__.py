@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get("WP_LIB") or os.path.join(_HERE, "libwordpiece_amd.so"
 
 WP_OPT_FULL_DEPTH, WP_OPT_DEVICE, WP_OPT_KEEP_DEBUG, WP_OPT_STAGE_TIMING, WP_OPT_LCP_KASAI = 1, 2, 3, 4, 5
 WP_OPT_FUSED_RERANK, WP_OPT_COVER_ANCHORS, WP_OPT_ARENA_GUARD, WP_OPT_DEVICES, WP_OPT_VOCAB_IN_S = 6, 7, 8, 9, 10
+WP_OPT_SPARSE_EMIT = 11
 
 # every symbol include/wordpiece_amd.h declares (checked by the CPU test-suite)
 ABI_SYMBOLS = [
@@ -50,7 +51,7 @@ class Stats(C.Structure):
                 ("n_anchors", C.c_int64), ("anchor_mode", C.c_int32), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double),
                 ("radix_digit_bytes", C.c_int64), ("ms_host_total", C.c_double), ("guard_zones", C.c_int32),
                 ("n_devices", C.c_int32), ("vocab_in_s", C.c_int32), ("reserved0", C.c_int32),
-                ("needed_after_round0", C.c_int64), ("key_bits", C.c_int32), ("reserved1", C.c_int32)]
+                ("needed_after_round0", C.c_int64), ("key_bits", C.c_int32), ("staged_emit", C.c_int32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "active_per_round"}

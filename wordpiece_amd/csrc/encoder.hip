@@ -180,6 +180,7 @@ struct wp_vocab {
   int device = -1;
   bool full_depth = false, keep_debug = false, stage_timing = false, lcp_kasai = false, fused_rerank = false, cover_anchors = false;
   bool arena_guard = false;
+  bool sparse_emit = false;  // WP_OPT_SPARSE_EMIT: ids through the per-position emit array even where per-workgroup lists would do
   bool vocab_in_s = false;  // WP_OPT_VOCAB_IN_S: always the reference's S = text . 1 . vocab layout
   int n_devices = 1;  // WP_OPT_DEVICES: GPUs wp_linear_encode shards a host buffer over (-1: all visible)
   wp_stats stats{};
@@ -477,6 +478,11 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   const size_t rr_tiles = cdiv(n, kRrTile);
   const size_t radix_words = std::max(radix_tmp_words<uint64_t>(n), radix_tmp_words<uint32_t>(std::max<size_t>(n, kStepsPerMark * std::max(M, 1) + 1)));
   const size_t emit_tiles = cdiv(std::max<size_t>(n_text, 1), kScanTile);
+  const size_t walk_blocks = cdiv(std::max<size_t>(n_text, 1), kBlock);  // (at most one anchor per position)
+  // ids as per-workgroup lists (walk.h, StagedOut) unless several kernels contribute ids: decided here, except
+  // for long words, which only the anchor gaps reveal
+  static const bool env_sparse_emit = env_flag("WP_SPARSE_EMIT");
+  const bool staged_possible = !env_sparse_emit && !v->sparse_emit && !v->cover_anchors && hv.soft.empty();
 
   // digit bytes (radix_sort.h): the round-0 sort's histograms read 1 byte per key instead of 8
   static const bool env_no_digit_bytes = env_flag("WP_NO_DIGIT_BYTES");
@@ -495,7 +501,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   uint32_t *V0 = nullptr, *V1 = nullptr, *AS0 = nullptr, *AS1 = nullptr, *AG = nullptr, *d_sa = nullptr,
            *d_radix_tmp = nullptr, *d_mslot0 = nullptr, *d_mslot1 = nullptr, *d_midx0 = nullptr,
            *d_midx1 = nullptr, *d_minfo = nullptr, *d_tile_mlo = nullptr, *d_emit_cnt = nullptr,
-           *d_emit_tmp = nullptr;
+           *d_emit_tmp = nullptr, *d_blk_cnt = nullptr, *d_blk_off = nullptr;
   int32_t *d_lcp = nullptr, *d_mid = nullptr, *d_rf = nullptr, *d_rb = nullptr;
   RerankAgg *d_agg = nullptr, *d_chunk_agg = nullptr;
   uint32_t *d_ghead = nullptr, *d_large_id = nullptr, *d_large_off = nullptr, *d_lg_head = nullptr,
@@ -568,7 +574,9 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     d_anchor_cnt = ar.take<uint32_t>(emit_tiles + 1);
     d_anchor_tmp = ar.take<uint32_t>(cdiv(emit_tiles, kScanTile) + 8);
     d_emit_cnt = ar.take<uint32_t>(emit_tiles + 1);
-    d_emit_tmp = ar.take<uint32_t>(cdiv(emit_tiles, kScanTile) + 8);
+    d_emit_tmp = ar.take<uint32_t>(cdiv(walk_blocks, kScanTile) + 8);  // (walk_blocks >= emit_tiles)
+    d_blk_cnt = ar.take<uint32_t>(walk_blocks + 2);
+    d_blk_off = ar.take<uint32_t>(walk_blocks + 2);
     if (pass == 0) ar.commit();
   }
   ar.arm(st);
@@ -577,7 +585,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   auto launch_anchors = [&](bool do_fork) {
     if (do_fork) fork();
     const unsigned atiles = cdiv(n_text, kAnchorTile);
-    WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st2));
+    if (!staged_possible) WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st2));
     hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st2, d_cls,
                        static_cast<const uint8_t *>(nullptr), n_text, d_anchor_cnt);
     device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st2);
@@ -1007,6 +1015,8 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       max_anchor_gap = c->h_scalars[11];
     }
     const bool all_hard = hv.soft.empty();
+    const bool staged = staged_possible && max_anchor_gap <= kMaxAnchorGap;
+    if (staged_possible && !staged) WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st));  // long words after all
     if (!v->cover_anchors && all_hard && max_anchor_gap > kMaxAnchorGap) {
       // words longer than a lane should walk (walk.h, "long words"): pointer doubling instead
       LongWord *d_lw = reinterpret_cast<LongWord *>(LPOS);
@@ -1084,12 +1094,23 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     S.n_anchors = static_cast<int64_t>(n_anchors);
     // the anchor list and the cleared emit array were produced on the side stream; one lane per anchor
     // (a grid sized for the worst case, every position an anchor, costs 0.35 ms of empty workgroups)
-    hipLaunchKernelGGL(walk_kernel, dim3(cdiv(std::max<size_t>(n_anchors, 1), kBlock)), dim3(kBlock), 0, st, wa,
-                       d_anchors, c->d_scalars + 10, std::max<size_t>(n_anchors, 1));
-    const unsigned tiles = cdiv(n_text, kScanTile);
-    hipLaunchKernelGGL(emit_count_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt);
-    device_exclusive_scan(d_emit_cnt, d_emit_cnt, tiles, d_emit_tmp, c->d_scalars + 9, st);
-    hipLaunchKernelGGL(emit_write_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt, d_ids);
+    const size_t acap = std::max<size_t>(n_anchors, 1);
+    const unsigned wblocks = cdiv(acap, kBlock);
+    if (staged) {
+      int32_t *d_ctmp = reinterpret_cast<int32_t *>(K0);  // (the key buffers are free after the suffix sort)
+      hipLaunchKernelGGL(walk_staged_kernel, dim3(wblocks), dim3(kBlock), 0, st, wa, d_anchors, c->d_scalars + 10, acap,
+                         d_ctmp, d_blk_cnt);
+      device_exclusive_scan(d_blk_cnt, d_blk_off, wblocks, d_emit_tmp, c->d_scalars + 9, st);
+      hipLaunchKernelGGL(emit_gather_kernel, dim3(wblocks), dim3(kBlock), 0, st, d_anchors, c->d_scalars + 10, acap, d_ctmp,
+                         d_blk_cnt, d_blk_off, d_ids);
+    } else {
+      hipLaunchKernelGGL(walk_kernel, dim3(wblocks), dim3(kBlock), 0, st, wa, d_anchors, c->d_scalars + 10, acap);
+      const unsigned tiles = cdiv(n_text, kScanTile);
+      hipLaunchKernelGGL(emit_count_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt);
+      device_exclusive_scan(d_emit_cnt, d_emit_cnt, tiles, d_emit_tmp, c->d_scalars + 9, st);
+      hipLaunchKernelGGL(emit_write_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt, d_ids);
+    }
+    S.staged_emit = staged ? 1 : 0;
     WP_LAUNCH_CHECK();
   }
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[6], st));
@@ -1205,11 +1226,13 @@ static void encode_fast_on_device(const wp_vocab *v, Context *c, const uint8_t *
   if (n_text == 0) return;
 
   Arena ar(&c->b_buf, aa.guard);
-  const size_t tiles = cdiv(n_text, kScanTile), atiles = cdiv(n_text, kAnchorTile);
+  const size_t tiles = cdiv(n_text, kScanTile), atiles = cdiv(n_text, kAnchorTile), walk_blocks = cdiv(n_text, kBlock);
+  static const bool env_sparse_emit = env_flag("WP_SPARSE_EMIT");
+  const bool staged_possible = !env_sparse_emit && !v->sparse_emit;
   const uint32_t lw_cap = static_cast<uint32_t>(n_text / kMaxAnchorGap + 2);
   int32_t *d_emit = nullptr, *d_ids = nullptr, *d_lid = nullptr;
   uint32_t *d_anchors = nullptr, *d_anchor_cnt = nullptr, *d_anchor_tmp = nullptr, *d_emit_cnt = nullptr, *d_emit_tmp = nullptr,
-           *jump_a = nullptr, *jump_b = nullptr, *d_lw_off = nullptr, *d_lw_fail = nullptr;
+           *d_blk_cnt = nullptr, *d_blk_off = nullptr, *jump_a = nullptr, *jump_b = nullptr, *d_lw_off = nullptr, *d_lw_fail = nullptr;
   uint8_t *d_mark = nullptr;
   LongWord *d_lw = nullptr;
   for (int pass = 0; pass < 2; pass++) {
@@ -1219,7 +1242,9 @@ static void encode_fast_on_device(const wp_vocab *v, Context *c, const uint8_t *
     d_anchor_cnt = ar.take<uint32_t>(atiles + 1);
     d_anchor_tmp = ar.take<uint32_t>(cdiv(atiles, kScanTile) + 8);
     d_emit_cnt = ar.take<uint32_t>(tiles + 1);
-    d_emit_tmp = ar.take<uint32_t>(cdiv(tiles, kScanTile) + 8);
+    d_emit_tmp = ar.take<uint32_t>(cdiv(walk_blocks, kScanTile) + 8);
+    d_blk_cnt = ar.take<uint32_t>(walk_blocks + 2);
+    d_blk_off = ar.take<uint32_t>(walk_blocks + 2);
     d_lid = ar.take<int32_t>(n_text + 1);
     jump_a = ar.take<uint32_t>(n_text + 1);
     jump_b = ar.take<uint32_t>(n_text + 1);
@@ -1233,7 +1258,6 @@ static void encode_fast_on_device(const wp_vocab *v, Context *c, const uint8_t *
   hipLaunchKernelGGL(HIP_KERNEL_NAME(decode_write_kernel<uint32_t>), dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes,
                      d_tile_cnt, static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), d_cls, d_cps,
                      static_cast<const uint32_t *>(nullptr), 0, static_cast<uint32_t *>(nullptr), 0);
-  WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st));
   hipLaunchKernelGGL(fast_anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, n_text, d_anchor_cnt);
   device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st);
   hipLaunchKernelGGL(fast_anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, n_text, d_anchor_cnt, d_anchors);
@@ -1248,6 +1272,9 @@ static void encode_fast_on_device(const wp_vocab *v, Context *c, const uint8_t *
               TrieView{c->d_trie_key, c->d_trie_child, c->d_trie_id, static_cast<uint32_t>(hv.trie_key.size() - 1)},
               c->d_tok_len, hv.unk_id, static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(hv.fast_max_len), n_text)),
               d_emit};
+  // ids as per-workgroup lists (walk.h, StagedOut) unless the long-word kernels contribute ids of their own
+  const bool staged = staged_possible && max_gap <= kMaxAnchorGap;
+  if (!staged) WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st));
   if (max_gap > kMaxAnchorGap) {  // long words: pointer doubling instead of one lane per word (walk.h)
     hipLaunchKernelGGL(fast_long_word_collect_kernel, dim3(std::min<size_t>(cdiv(std::max<size_t>(n_anchors, 1), kBlock), 2048)),
                        dim3(kBlock), 0, st, d_anchors, c->d_scalars + 10, n_text, d_cls, d_lw, lw_cap, c->d_scalars + 12);
@@ -1288,11 +1315,21 @@ static void encode_fast_on_device(const wp_vocab *v, Context *c, const uint8_t *
       S.anchor_mode = 2;
     }
   }
-  hipLaunchKernelGGL(fast_walk_kernel, dim3(cdiv(std::max<size_t>(n_anchors, 1), kBlock)), dim3(kBlock), 0, st, fa, d_anchors,
-                     c->d_scalars + 10, std::max<size_t>(n_anchors, 1));
-  hipLaunchKernelGGL(emit_count_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt);
-  device_exclusive_scan(d_emit_cnt, d_emit_cnt, tiles, d_emit_tmp, c->d_scalars + 9, st);
-  hipLaunchKernelGGL(emit_write_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt, d_ids);
+  const size_t acap = std::max<size_t>(n_anchors, 1);
+  const unsigned wblocks = cdiv(acap, kBlock);
+  if (staged) {
+    hipLaunchKernelGGL(fast_walk_staged_kernel, dim3(wblocks), dim3(kBlock), 0, st, fa, d_anchors, c->d_scalars + 10, acap,
+                       d_lid, d_blk_cnt);  // (d_lid: the long-word id buffer, idle here)
+    device_exclusive_scan(d_blk_cnt, d_blk_off, wblocks, d_emit_tmp, c->d_scalars + 9, st);
+    hipLaunchKernelGGL(emit_gather_kernel, dim3(wblocks), dim3(kBlock), 0, st, d_anchors, c->d_scalars + 10, acap, d_lid,
+                       d_blk_cnt, d_blk_off, d_ids);
+  } else {
+    hipLaunchKernelGGL(fast_walk_kernel, dim3(wblocks), dim3(kBlock), 0, st, fa, d_anchors, c->d_scalars + 10, acap);
+    hipLaunchKernelGGL(emit_count_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt);
+    device_exclusive_scan(d_emit_cnt, d_emit_cnt, tiles, d_emit_tmp, c->d_scalars + 9, st);
+    hipLaunchKernelGGL(emit_write_kernel, dim3(tiles), dim3(kBlock), 0, st, d_emit, n_text, d_emit_cnt, d_ids);
+  }
+  S.staged_emit = staged ? 1 : 0;
   WP_LAUNCH_CHECK();
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[3], st));
   if (ar.guard) {
@@ -1427,6 +1464,7 @@ int wp_set_option(wp_vocab *v, int option, int64_t value) {
     case WP_OPT_COVER_ANCHORS: v->cover_anchors = value != 0; return WP_OK;
     case WP_OPT_ARENA_GUARD: v->arena_guard = value != 0; return WP_OK;
     case WP_OPT_VOCAB_IN_S: v->vocab_in_s = value != 0; return WP_OK;
+    case WP_OPT_SPARSE_EMIT: v->sparse_emit = value != 0; return WP_OK;
     case WP_OPT_DEVICES: v->n_devices = value < 0 ? -1 : static_cast<int>(std::max<int64_t>(value, 1)); return WP_OK;
   }
   g_last_error = "unknown option";

@@ -90,26 +90,27 @@ __device__ __forceinline__ int32_t f_match(const FastArgs &a, size_t p) {
   return best;
 }
 
-__device__ inline void fast_walk_from(const FastArgs &a, size_t p) {
+template <typename Out>
+__device__ inline void fast_walk_from(const FastArgs &a, size_t p, Out &o) {
   const size_t end = a.n_text;
   size_t since = p;  // start of the tokens counted by tokens_since_prefix
+  o.word_start();
   while (p < end) {
     const int32_t id = f_match(a, p);
     if (id != -1) {
-      a.emit[p] = id;
+      o.push(p, id);
       p += static_cast<size_t>(a.tok_len[id]);
-      if (p < end && f_word_prefix(a, p)) since = p;  // fast.cpp:90-92
-    } else {  // fast.cpp:80-89: roll the word's tokens back, [UNK], skip the rest of the word
-      size_t q = since;
-      while (q < p) {
-        const int32_t t = a.emit[q];
-        a.emit[q] = kNoEmit;
-        q += static_cast<size_t>(a.tok_len[t]);
+      if (p < end && f_word_prefix(a, p)) {  // fast.cpp:90-92
+        since = p;
+        o.word_start();
       }
-      a.emit[p] = a.unk_id;
+    } else {  // fast.cpp:80-89: roll the word's tokens back, [UNK], skip the rest of the word
+      o.rollback(since, p);
+      o.push(p, a.unk_id);
       p += f_word_len(a, p);
       while (p < end && !f_word_prefix(a, p)) ++p;
       since = p;
+      o.word_start();
     }
     // behind a space the next non-space position is an anchor of its own (fast.cpp:94-96 skips the run)
     if (p >= end || (a.cls[p] & kClsSpace) || f_anchor(a, p)) return;
@@ -264,7 +265,28 @@ __global__ __launch_bounds__(kBlock) void fast_walk_kernel(FastArgs a, const uin
   if (k >= cap || k >= *n_anchors_dev) return;
   const uint32_t start = anchors[k];
   if (start & kAnchorSkip) return;  // a long word: fast_long_word_* kernels
-  fast_walk_from(a, start);
+  SparseOut o{a.emit, a.tok_len};
+  fast_walk_from(a, start, o);
+}
+
+// no long word in the text: the ids leave as per-workgroup lists (walk.h, StagedOut)
+__global__ __launch_bounds__(kBlock) void fast_walk_staged_kernel(FastArgs a, const uint32_t *__restrict__ anchors,
+                                                                  const uint32_t *__restrict__ n_anchors_dev, size_t cap,
+                                                                  int32_t *__restrict__ ctmp,
+                                                                  uint32_t *__restrict__ blk_cnt) {
+  __shared__ int32_t stage[kStageIds * kBlock];
+  __shared__ uint32_t sm[8];
+  const size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const size_t na = min(cap, static_cast<size_t>(*n_anchors_dev));
+  const size_t k0 = static_cast<size_t>(blockIdx.x) * kBlock;
+  const size_t base = k0 < na ? anchors[k0] : 0;
+  StagedOut o{stage + threadIdx.x, a.emit, 0, 0};
+  if (k < na) {
+    const uint32_t start = anchors[k];
+    o.spill = a.emit + start;
+    fast_walk_from(a, start, o);
+  }
+  flush_staged(o, base, ctmp, blk_cnt, sm);
 }
 
 }  // namespace wp

@@ -46,9 +46,64 @@ __device__ __forceinline__ bool w_anchor(const WalkArgs &a, size_t p) {
   return p == 0 || w_hard(c) || w_hard(a.cls[p - 1]);
 }
 
-__device__ inline void walk_from(const WalkArgs &a, size_t p) {
+// ---- where a lane's ids go ---------------------------------------------------------------------------
+// SparseOut: emit[p] = id at the token's first position; emit_count / emit_write compact the array afterwards
+// (needed when several kernels contribute ids: long words, coverage anchors).
+// StagedOut: the lane keeps its ids — the first kStageIds in LDS, the rest at emit[p0 + j], inside the stretch
+// of text only this lane walks — and the workgroup appends them, lane after lane, to a compact list that
+// starts at the position of its first anchor (a token consumes at least one position, so the list fits in
+// front of the next workgroup's first anchor).  emit_gather_kernel then moves whole lists: the id stream is
+// written and read once, 4 bytes per id, instead of a cleared 4-byte slot per text position.
+constexpr int kStageIds = 4;
+
+struct SparseOut {
+  int32_t *emit;
+  const int32_t *tok_len;
+  __device__ __forceinline__ void push(size_t p, int32_t id) { emit[p] = id; }
+  __device__ __forceinline__ void word_start() {}
+  __device__ __forceinline__ void rollback(size_t since, size_t p) {  // linear.cpp:257-262, fast.cpp:80-89
+    size_t q = since;
+    while (q < p) {
+      const int32_t t = emit[q];
+      emit[q] = kNoEmit;
+      q += static_cast<size_t>(tok_len[t]);
+    }
+  }
+};
+
+struct StagedOut {
+  int32_t *stage;  // LDS: this lane's column, stride kBlock
+  int32_t *spill;  // emit + p0
+  uint32_t c = 0, mark = 0;
+  __device__ __forceinline__ void push(size_t, int32_t id) {
+    if (c < static_cast<uint32_t>(kStageIds)) {
+      stage[c * kBlock] = id;
+    } else {
+      spill[c] = id;
+    }
+    c++;
+  }
+  __device__ __forceinline__ void word_start() { mark = c; }
+  __device__ __forceinline__ void rollback(size_t, size_t) { c = mark; }
+  __device__ __forceinline__ int32_t get(uint32_t j) const {
+    return j < static_cast<uint32_t>(kStageIds) ? stage[j * kBlock] : spill[j];
+  }
+};
+
+// the workgroup's lists, one behind the other, at ctmp[base...]; blk_cnt[block] = their total length
+__device__ __forceinline__ void flush_staged(const StagedOut &o, size_t base, int32_t *__restrict__ ctmp,
+                                             uint32_t *__restrict__ blk_cnt, uint32_t *sm) {
+  uint32_t tot;
+  const uint32_t ex = block_excl_sum(o.c, sm, tot);
+  for (uint32_t j = 0; j < o.c; j++) ctmp[base + ex + j] = o.get(j);
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
+}
+
+template <typename Out>
+__device__ inline void walk_from(const WalkArgs &a, size_t p, Out &o) {
   const size_t end = a.n_text;
   size_t since = p;  // start of the tokens counted by tokens_since_prefix
+  o.word_start();
   while (p < end) {
     const bool prefix = w_word_prefix(a, p);
     const uint32_t r = rank_of(a.rank[p]);
@@ -56,18 +111,16 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
     int32_t id = prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
     if (!wp_in_bounds(id >= -1 && id < a.n_tokens, kSiteTokenId)) id = -1;
     if (id != -1) {
-      a.emit[p] = id;
+      o.push(p, id);
       p += static_cast<size_t>(a.tok_len[id]);
-      if (p < end && w_word_prefix(a, p)) since = p;
+      if (p < end && w_word_prefix(a, p)) {
+        since = p;
+        o.word_start();
+      }
     } else {
       // roll back this word's tokens (linear.cpp:257-262), then [UNK]
-      size_t q = since;
-      while (q < p) {
-        const int32_t t = a.emit[q];
-        a.emit[q] = kNoEmit;
-        q += static_cast<size_t>(a.tok_len[t]);
-      }
-      a.emit[p] = a.unk_id;
+      o.rollback(since, p);
+      o.push(p, a.unk_id);
       ++p;
       while (p < end && !w_word_prefix(a, p)) {
         ++p;
@@ -79,6 +132,7 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
         }
       }
       since = p;
+      o.word_start();
     }
     if (p < end && w_space(a, p)) {
       // class rule with only hard spacing chars: the first position behind the spaces is an anchor of
@@ -95,7 +149,10 @@ __device__ inline void walk_from(const WalkArgs &a, size_t p) {
     }
     if (p >= end || w_anchor(a, p)) return;
     // after skipped spaces p is a word-prefix position: counter restarts
-    if (w_word_prefix(a, p)) since = p;
+    if (w_word_prefix(a, p)) {
+      since = p;
+      o.word_start();
+    }
   }
 }
 
@@ -454,12 +511,48 @@ __global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a, const uint32_t
     // the coverage rule, a word-prefix position no match reaches, since spaces match nothing.)
     size_t q = 0;
     while (q < a.n_text && w_space(a, q)) ++q;
-    if (q < a.n_text && q != 0 && !w_anchor(a, q)) walk_from(a, q);
+    SparseOut o{a.emit, a.tok_len};
+    if (q < a.n_text && q != 0 && !w_anchor(a, q)) walk_from(a, q, o);
   }
   if (k >= cap || k >= *n_anchors_dev) return;
   const uint32_t start = anchors[k];
   if (start & kAnchorSkip) return;  // a long word: long_word_* kernels
-  walk_from(a, start);
+  SparseOut o{a.emit, a.tok_len};
+  walk_from(a, start, o);
+}
+
+// Class-rule anchors with only hard spacing chars and no long word (the common case): every lane walks exactly
+// one word, and the ids leave the kernel as per-workgroup lists (StagedOut).
+__global__ __launch_bounds__(kBlock) void walk_staged_kernel(WalkArgs a, const uint32_t *__restrict__ anchors,
+                                                             const uint32_t *__restrict__ n_anchors_dev, size_t cap,
+                                                             int32_t *__restrict__ ctmp, uint32_t *__restrict__ blk_cnt) {
+  __shared__ int32_t stage[kStageIds * kBlock];
+  __shared__ uint32_t sm[8];
+  const size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const size_t na = min(cap, static_cast<size_t>(*n_anchors_dev));
+  const size_t k0 = static_cast<size_t>(blockIdx.x) * kBlock;
+  const size_t base = k0 < na ? anchors[k0] : 0;
+  StagedOut o{stage + threadIdx.x, a.emit, 0, 0};
+  if (k < na) {
+    const uint32_t start = anchors[k];
+    o.spill = a.emit + start;
+    walk_from(a, start, o);
+  }
+  flush_staged(o, base, ctmp, blk_cnt, sm);
+}
+
+// ids[blk_off[b] ...] = the list of workgroup b
+__global__ __launch_bounds__(kBlock) void emit_gather_kernel(const uint32_t *__restrict__ anchors,
+                                                             const uint32_t *__restrict__ n_anchors_dev, size_t cap,
+                                                             const int32_t *__restrict__ ctmp,
+                                                             const uint32_t *__restrict__ blk_cnt,
+                                                             const uint32_t *__restrict__ blk_off,
+                                                             int32_t *__restrict__ ids) {
+  const size_t k0 = static_cast<size_t>(blockIdx.x) * kBlock;
+  if (k0 >= cap || k0 >= *n_anchors_dev) return;
+  const size_t base = anchors[k0], off = blk_off[blockIdx.x];
+  const uint32_t cnt = blk_cnt[blockIdx.x];
+  for (uint32_t j = threadIdx.x; j < cnt; j += kBlock) ids[off + j] = ctmp[base + j];
 }
 
 // ---- compaction of emit[] into the id stream ----------------------------------------------------
