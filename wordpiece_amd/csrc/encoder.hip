@@ -534,7 +534,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     AD1 = ar.take<uint32_t>(n);
     d_tdep = ar.take<uint32_t>(n + 2 + rr_tiles * 4 + 8);  // (tail: look-back state of the fused rerank)
     d_gdepth = ar.take<uint32_t>(n);
-    d_lcp = ar.take<int32_t>(n);
+    d_lcp = (text_only && !v->keep_debug) ? nullptr : ar.take<int32_t>(n);  // (text-only layout: nothing reads the LCPs)
     d_radix_tmp = ar.take<uint32_t>(radix_words);
     d_ghead = ar.take<uint32_t>(n / 2 + 4);
     d_large_id = ar.take<uint32_t>(n / 2 + 4);
@@ -779,8 +779,15 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       }
       hipLaunchKernelGGL(needed_list_close_kernel, dim3(1), dim3(1), 0, st2, c->d_scalars + 4, d_ghead);
       if (M > 0) hipLaunchKernelGGL(needed_fill_kernel, dim3(1024), dim3(kBlock), 0, st2, nl, vals, n);
-      hipLaunchKernelGGL(round0_rank_kernel, dim3(cdiv(n, kR0Tile)), dim3(kBlock), 0, st, keys, vals, n, dcode.first_len,
-                         dcode.uniform_bits, (v->keep_debug || v->lcp_kasai) ? d_sa : nullptr, hd, d_lcp, d_gdepth);
+      if (d_lcp) {
+        hipLaunchKernelGGL(round0_rank_kernel<true>, dim3(cdiv(n, kR0Tile)), dim3(kBlock), 0, st, keys, vals, n,
+                           dcode.first_len, dcode.uniform_bits, (v->keep_debug || v->lcp_kasai) ? d_sa : nullptr, hd, d_lcp,
+                           d_gdepth);
+      } else {
+        hipLaunchKernelGGL(round0_rank_kernel<false>, dim3(cdiv(n, kR0Tile)), dim3(kBlock), 0, st, keys, vals, n,
+                           dcode.first_len, dcode.uniform_bits, (v->keep_debug || v->lcp_kasai) ? d_sa : nullptr, hd, d_lcp,
+                           d_gdepth);
+      }
       join();  // the rank store below reuses the key buffer as scratch: the searches in it must be over
     } else if (fused_rerank) {
       WP_HIP(hipMemsetAsync(lb.wa, 0, lb_bytes, st));

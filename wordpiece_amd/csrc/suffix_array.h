@@ -434,7 +434,9 @@ __device__ __forceinline__ void rr_second_half(const RrTile &T, const uint64_t *
       } else if (f && !single) {
         gdepth[x] = nd;  // x is the first slot of this (still tied) group
       }
-      if (ROUND0) {
+      if (!lcp) {
+        // (text-only layout: nothing reads the LCPs, and the symbol compare below is two gathers per boundary)
+      } else if (ROUND0) {
         if (k > 0) {
           int32_t l = -1;
           if (f) l = count_key_symbols(T.mes[r], static_cast<int>(T.nds[r] >> 16) - (64 - kKeyBits), s_fl, uniform_bits);
@@ -540,6 +542,9 @@ constexpr int kR0Vec = 16 / static_cast<int>(sizeof(Key0)) * 2;  // 8 entries (u
 constexpr int kR0Steps = 2;
 constexpr int kR0WaveSpan = kWave * kR0Vec * kR0Steps;
 constexpr int kR0Tile = (kBlock / kWave) * kR0WaveSpan;
+// LCP = false: no LCP array (the text-only layout takes the tokens' reach from their ranges in the sorted keys,
+// nothing reads the LCPs): 4 bytes read and 4 written per entry.
+template <bool LCP>
 __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restrict__ keys,
                                                              const uint32_t *__restrict__ vals, size_t n,
                                                              const uint8_t *__restrict__ first_len, int uniform_bits,
@@ -627,7 +632,7 @@ __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restr
       // boundary between slot k0 + j and the next one
       const uint64_t nx = j + 1 < kR0Vec ? me[t][j + 1 < kR0Vec ? j + 1 : j] : nextk;
       int32_t l = -1;
-      if (k0 + j + 1 < n && nx != me[t][j]) {
+      if (LCP && k0 + j + 1 < n && nx != me[t][j]) {
         l = count_key_symbols(nx, __clzll(static_cast<long long>(nx ^ me[t][j])) - (64 - kKeyBits), s_fl, uniform_bits);
       }
       lv[j] = l;
@@ -642,15 +647,17 @@ __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restr
 #pragma unroll
       for (int q = 0; q < kR0Vec / 4; q++) {
         hdst[q] = make_uint4(hv[4 * q], hv[4 * q + 1], hv[4 * q + 2], hv[4 * q + 3]);
-        ldst[q] = make_uint4(static_cast<uint32_t>(lv[4 * q]), static_cast<uint32_t>(lv[4 * q + 1]),
-                             static_cast<uint32_t>(lv[4 * q + 2]), static_cast<uint32_t>(lv[4 * q + 3]));
+        if (LCP) {
+          ldst[q] = make_uint4(static_cast<uint32_t>(lv[4 * q]), static_cast<uint32_t>(lv[4 * q + 1]),
+                               static_cast<uint32_t>(lv[4 * q + 2]), static_cast<uint32_t>(lv[4 * q + 3]));
+        }
       }
     } else {
 #pragma unroll
       for (int j = 0; j < kR0Vec; j++) {
         if (k0 + j < n) {
           hd[k0 + j] = hv[j];
-          if (k0 + j + 1 < n) lcp[k0 + j] = lv[j];
+          if (LCP && k0 + j + 1 < n) lcp[k0 + j] = lv[j];
         }
       }
     }
