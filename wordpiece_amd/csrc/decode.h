@@ -261,6 +261,31 @@ __device__ __forceinline__ int count_key_symbols(uint64_t key, int t, const uint
   return cnt;
 }
 
+// First index in [lo, hi] whose key is >= key (hi: a position known to qualify, or the end of the array), by a
+// 64-way search of the whole wave: every step the lanes probe 64 evenly spaced positions with ONE load
+// instruction and a ballot picks the stretch that holds the answer — 5 dependent loads for 1e8 sorted keys
+// instead of the 27 of a binary search (the searches of this path are latency chains, not bandwidth).
+// All 64 lanes must be active; every lane returns the same index.
+__device__ __forceinline__ size_t wave_key_lower_bound(const Key0 *__restrict__ keys, size_t lo, size_t hi, uint64_t key) {
+  const size_t lane = static_cast<size_t>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+  while (lo < hi) {
+    const size_t st = (hi - lo) / kWave + 1;
+    const size_t idx = lo + lane * st;
+    const bool ge = idx < hi ? static_cast<uint64_t>(keys[idx]) >= key : true;
+    const uint64_t m = __ballot(ge);
+    if (!m) {  // (all 64 probes in range and below the key)
+      lo += (kWave - 1) * st + 1;
+      continue;
+    }
+    const size_t t = static_cast<size_t>(__ffsll(static_cast<long long>(m)) - 1);
+    const size_t first_ge = lo + t * st;
+    if (t) lo += (t - 1) * st + 1;
+    hi = first_ge < hi ? first_ge : hi;
+    if (!t) hi = lo;
+  }
+  return lo;
+}
+
 // Round-0 keys: the first 63 bits of the codeword stream of every suffix (most significant bit
 // first).  Positions past the end read symbol 0, whose codeword is the smallest, so a shorter
 // suffix sorts first.

@@ -541,7 +541,8 @@ __global__ __launch_bounds__(kBlock) void widen_keys_kernel(const Key0 *__restri
 constexpr int kR0Vec = 16 / static_cast<int>(sizeof(Key0)) * 2;  // 8 entries (u32 keys: 2 x uint4) or 4 (u64 keys: 2 x 16 B)
 constexpr int kR0Steps = 2;
 constexpr int kR0WaveSpan = kWave * kR0Vec * kR0Steps;
-constexpr int kR0Tile = (kBlock / kWave) * kR0WaveSpan;
+constexpr int kR0Spans = 4;  // spans a wave takes one after the other: the decode table is staged once per workgroup
+constexpr int kR0Tile = (kBlock / kWave) * kR0WaveSpan * kR0Spans;
 // LCP = false: no LCP array (the text-only layout takes the tokens' reach from their ranges in the sorted keys,
 // nothing reads the LCPs): 4 bytes read and 4 written per entry.
 template <bool LCP>
@@ -551,128 +552,171 @@ __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restr
                                                              uint32_t *__restrict__ sa_dbg, RankEntry *__restrict__ hd,
                                                              int32_t *__restrict__ lcp, uint32_t *__restrict__ gdepth) {
   __shared__ uint8_t s_fl[kDecodeTableBytes];
+  // Heads of tied groups need their key's symbol count (a table walk of ~14 steps).  Done where the head is found,
+  // every wave ran that walk 16 times per span with a few lanes active (137 VALU instructions per entry, the
+  // kernel was VALU bound); instead the heads of a step are listed in LDS and the wave walks the list densely.
+  // (a tied head is followed by an entry that is no head: at most half of a step's entries)
+  constexpr int kHeadCap = kWave * kR0Vec / 2;
+  __shared__ uint32_t s_hpos[kBlock / kWave][kHeadCap];
+  __shared__ Key0 s_hkey[kBlock / kWave][kHeadCap];
   const int lane = lane_id(), w = wave_id();
-  const size_t wave_base = static_cast<size_t>(blockIdx.x) * kR0Tile + static_cast<size_t>(w) * kR0WaveSpan;
-  // all loads of the wave are issued before anything waits (~0 is never a key: registers hold 64 bits)
-  uint64_t me[kR0Steps][kR0Vec];
-#pragma unroll
-  for (int t = 0; t < kR0Steps; t++) {
-    const size_t k0 = wave_base + (static_cast<size_t>(t) * kWave + lane) * kR0Vec;
-    if (k0 + kR0Vec <= n) {  // (the key buffer is 256-byte aligned and k0 a multiple of kR0Vec: aligned 16-byte loads)
-      Key0 tmp[kR0Vec];
-      const uint4 *src = reinterpret_cast<const uint4 *>(keys + k0);
-      uint4 a = src[0], b = src[1];
-      __builtin_memcpy(tmp, &a, 16);
-      __builtin_memcpy(reinterpret_cast<char *>(tmp) + 16, &b, 16);
-#pragma unroll
-      for (int j = 0; j < kR0Vec; j++) me[t][j] = static_cast<uint64_t>(tmp[j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < kR0Vec; j++) me[t][j] = k0 + j < n ? static_cast<uint64_t>(keys[k0 + j]) : ~0ull;
-    }
-  }
-  const bool have_front = wave_base < n && wave_base >= 1 + static_cast<size_t>(lane);
-  const uint64_t front = have_front ? static_cast<uint64_t>(keys[wave_base - 1 - lane]) : ~0ull;  // lane l: the key l + 1 entries in front
-  const size_t after_idx = wave_base + kR0WaveSpan;
-  const uint64_t after = after_idx < n ? static_cast<uint64_t>(keys[after_idx]) : ~0ull;  // (one broadcast load)
+  volatile uint32_t *hpos = s_hpos[w];
+  volatile Key0 *hkey = s_hkey[w];
   if (uniform_bits <= 0) {
     for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
       reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
     }
   }
   __syncthreads();
-  if (wave_base >= n) return;
-  size_t carry = wave_base;  // head of the group of the entries in front of the first head seen by this wave
-  {
-    const uint64_t me0 = __shfl(me[0][0], 0, kWave);
-    const uint64_t neq = ~__ballot(have_front && front == me0);
-    if (neq & 1ull) {
-      carry = wave_base;  // the entry in front has another key (or there is none): the wave starts a group
-    } else if (neq) {
-      carry = wave_base - static_cast<size_t>(__ffsll(static_cast<long long>(neq)) - 1);
-    } else {  // a group of more than 64 entries reaches in: its first entry by binary search
-      size_t lo = 0, hi = wave_base - kWave;
-      while (lo < hi) {
-        const size_t md = (lo + hi) >> 1;
-        if (static_cast<uint64_t>(keys[md]) < me0) lo = md + 1; else hi = md;
+  // (keys stay in registers of their own width; entries past the end are masked by index, never by value)
+  auto wide = [](Key0 k) { return static_cast<uint64_t>(k); };
+  for (int sp = 0; sp < kR0Spans; sp++) {
+    const size_t wave_base = static_cast<size_t>(blockIdx.x) * kR0Tile +
+                             (static_cast<size_t>(sp) * (kBlock / kWave) + w) * kR0WaveSpan;
+    if (wave_base >= n) return;  // (wave-uniform; no barrier behind this point)
+    // all loads of the span are issued before anything waits
+    Key0 me[kR0Steps][kR0Vec];
+#pragma unroll
+    for (int t = 0; t < kR0Steps; t++) {
+      const size_t k0 = wave_base + (static_cast<size_t>(t) * kWave + lane) * kR0Vec;
+      if (k0 + kR0Vec <= n) {  // (the key buffer is 256-byte aligned and k0 a multiple of kR0Vec: aligned 16-byte loads)
+        const uint4 *src = reinterpret_cast<const uint4 *>(keys + k0);
+        uint4 a = src[0], b = src[1];
+        __builtin_memcpy(&me[t][0], &a, 16);
+        __builtin_memcpy(reinterpret_cast<char *>(&me[t][0]) + 16, &b, 16);
+      } else {
+#pragma unroll
+        for (int j = 0; j < kR0Vec; j++) me[t][j] = k0 + j < n ? keys[k0 + j] : static_cast<Key0>(0);
       }
-      carry = lo;
     }
-  }
-  uint64_t prev_last = __shfl(front, 0, kWave);  // key of the entry in front of the current step
-#pragma unroll
-  for (int t = 0; t < kR0Steps; t++) {
-    const size_t k0 = wave_base + (static_cast<size_t>(t) * kWave + lane) * kR0Vec;
-    const uint64_t up = __shfl_up(me[t][kR0Vec - 1], 1, kWave), dn = __shfl_down(me[t][0], 1, kWave);
-    const uint64_t next_first = t + 1 < kR0Steps ? __shfl(me[t + 1 < kR0Steps ? t + 1 : t][0], 0, kWave) : after;
-    const uint64_t prevk = lane == 0 ? prev_last : up;
-    const uint64_t nextk = lane == kWave - 1 ? next_first : dn;
-    // flags of the lane's entries; the last head inside the lane
-    bool f[kR0Vec];
-    int last = -1;
-#pragma unroll
-    for (int j = 0; j < kR0Vec; j++) {
-      const uint64_t p = j == 0 ? prevk : me[t][j - 1];
-      f[j] = k0 + j < n && p != me[t][j];
-      if (f[j]) last = j;
-    }
-    // head carried into the lane: the last head of the nearest lower lane that has one, else the wave's carry
-    const uint64_t bh = __ballot(last >= 0);
-    const uint64_t lower = bh & ((1ull << lane) - 1ull);
-    const int src_lane = lower ? 63 - __clzll(static_cast<long long>(lower)) : 0;
-    const uint32_t my_last_pos = static_cast<uint32_t>(k0 + (last >= 0 ? last : 0));
-    const uint32_t from_lane = __shfl(my_last_pos, src_lane, kWave);
-    size_t head = lower ? static_cast<size_t>(from_lane) : carry;
-    uint32_t hv[kR0Vec];
-    int32_t lv[kR0Vec];
-#pragma unroll
-    for (int j = 0; j < kR0Vec; j++) {
-      if (f[j]) head = k0 + j;
-      hv[j] = static_cast<uint32_t>(head);
-      // boundary between slot k0 + j and the next one
-      const uint64_t nx = j + 1 < kR0Vec ? me[t][j + 1 < kR0Vec ? j + 1 : j] : nextk;
-      int32_t l = -1;
-      if (LCP && k0 + j + 1 < n && nx != me[t][j]) {
-        l = count_key_symbols(nx, __clzll(static_cast<long long>(nx ^ me[t][j])) - (64 - kKeyBits), s_fl, uniform_bits);
-      }
-      lv[j] = l;
-      if (f[j]) {  // head of a tied group (the next entry has the same key): its depth
-        if (k0 + j + 1 < n && nx == me[t][j]) {
-          gdepth[k0 + j] = static_cast<uint32_t>(count_key_symbols(me[t][j], kKeyBits, s_fl, uniform_bits));
+    const bool have_front = wave_base >= 1 + static_cast<size_t>(lane);
+    const Key0 front = have_front ? keys[wave_base - 1 - lane] : static_cast<Key0>(0);  // lane l: the key l + 1 entries in front
+    const size_t after_idx = wave_base + kR0WaveSpan;
+    const Key0 after = after_idx < n ? keys[after_idx] : static_cast<Key0>(0);  // (one broadcast load)
+    size_t carry = wave_base;  // head of the group of the entries in front of the first head seen by this wave
+    {
+      const Key0 me0 = __shfl(me[0][0], 0, kWave);
+      const uint64_t neq = ~__ballot(have_front && front == me0);
+      if (neq & 1ull) {
+        carry = wave_base;  // the entry in front has another key (or there is none): the wave starts a group
+      } else if (neq) {
+        carry = wave_base - static_cast<size_t>(__ffsll(static_cast<long long>(neq)) - 1);
+      } else {
+        // a group of more than 64 entries reaches in.  Its first entry: gallop backwards (64 probes per load,
+        // 64, 4096, 262144, ... entries apart) to the stretch where the keys change, then the 64-way search —
+        // two dependent loads for groups of up to 4096 entries, where a binary search from the front of the
+        // array took 27 and made this kernel a latency chain (most spans start inside a large group)
+        size_t hi = wave_base - kWave, lo = 0, step = kWave;  // keys[hi] == me0
+        for (;;) {
+          const size_t back = step * static_cast<size_t>(lane + 1);
+          const bool valid = hi >= back;
+          const bool eq = valid && keys[hi - back] == me0;
+          const uint64_t nm = ~__ballot(eq);
+          if (nm) {  // the nearest probe with another key (or in front of the array)
+            const size_t t = static_cast<size_t>(__ffsll(static_cast<long long>(nm)) - 1);
+            lo = hi >= step * (t + 1) ? hi - step * (t + 1) + 1 : 0;
+            hi -= step * t;
+            break;
+          }
+          hi -= step * kWave;
+          step *= kWave;
         }
+        carry = wave_key_lower_bound(keys, lo, hi, static_cast<uint64_t>(me0));
       }
     }
-    if (k0 + kR0Vec <= n) {
-      uint4 *hdst = reinterpret_cast<uint4 *>(hd + k0), *ldst = reinterpret_cast<uint4 *>(lcp + k0);
+    Key0 prev_last = __shfl(front, 0, kWave);  // key of the entry in front of the current step
 #pragma unroll
-      for (int q = 0; q < kR0Vec / 4; q++) {
-        hdst[q] = make_uint4(hv[4 * q], hv[4 * q + 1], hv[4 * q + 2], hv[4 * q + 3]);
-        if (LCP) {
-          ldst[q] = make_uint4(static_cast<uint32_t>(lv[4 * q]), static_cast<uint32_t>(lv[4 * q + 1]),
-                               static_cast<uint32_t>(lv[4 * q + 2]), static_cast<uint32_t>(lv[4 * q + 3]));
-        }
-      }
-    } else {
+    for (int t = 0; t < kR0Steps; t++) {
+      const size_t k0 = wave_base + (static_cast<size_t>(t) * kWave + lane) * kR0Vec;
+      const Key0 up = __shfl_up(me[t][kR0Vec - 1], 1, kWave), dn = __shfl_down(me[t][0], 1, kWave);
+      const Key0 next_first = t + 1 < kR0Steps ? __shfl(me[t + 1 < kR0Steps ? t + 1 : t][0], 0, kWave) : after;
+      const Key0 prevk = lane == 0 ? prev_last : up;
+      const Key0 nextk = lane == kWave - 1 ? next_first : dn;
+      // flags of the lane's entries; the last head inside the lane
+      bool f[kR0Vec];
+      int last = -1;
 #pragma unroll
       for (int j = 0; j < kR0Vec; j++) {
-        if (k0 + j < n) {
-          hd[k0 + j] = hv[j];
-          if (LCP && k0 + j + 1 < n) lcp[k0 + j] = lv[j];
-        }
+        const Key0 p = j == 0 ? prevk : me[t][j - 1];
+        f[j] = k0 + j < n && (k0 + j == 0 || p != me[t][j]);
+        if (f[j]) last = j;
       }
-    }
-    if (sa_dbg) {
+      // head carried into the lane: the last head of the nearest lower lane that has one, else the wave's carry
+      const uint64_t bh = __ballot(last >= 0);
+      const uint64_t lower = bh & ((1ull << lane) - 1ull);
+      const int src_lane = lower ? 63 - __clzll(static_cast<long long>(lower)) : 0;
+      const uint32_t my_last_pos = static_cast<uint32_t>(k0 + (last >= 0 ? last : 0));
+      const uint32_t from_lane = __shfl(my_last_pos, src_lane, kWave);
+      size_t head = lower ? static_cast<size_t>(from_lane) : carry;
+      uint32_t hv[kR0Vec];
+      int32_t lv[kR0Vec];
+      uint32_t tied = 0;  // the lane's heads of tied groups
 #pragma unroll
       for (int j = 0; j < kR0Vec; j++) {
-        if (k0 + j < n) sa_dbg[k0 + j] = vals[k0 + j];
+        if (f[j]) head = k0 + j;
+        hv[j] = static_cast<uint32_t>(head);
+        // boundary between slot k0 + j and the next one
+        const Key0 nx = j + 1 < kR0Vec ? me[t][j + 1 < kR0Vec ? j + 1 : j] : nextk;
+        const bool has_next = k0 + j + 1 < n;
+        int32_t l = -1;
+        if (LCP && has_next && nx != me[t][j]) {
+          l = count_key_symbols(wide(nx), __clzll(static_cast<long long>(wide(nx) ^ wide(me[t][j]))) - (64 - kKeyBits), s_fl,
+                                uniform_bits);
+        }
+        lv[j] = l;
+        if (f[j] && has_next && nx == me[t][j]) tied |= 1u << j;  // (the next entry has the same key)
       }
+      {  // depth of the tied groups that start in this step
+        const uint32_t cnt = __popc(tied);
+        const uint32_t incl = wave_incl_sum(cnt);
+        const uint32_t total = __shfl(incl, kWave - 1, kWave);
+        uint32_t o = incl - cnt;
+#pragma unroll
+        for (int j = 0; j < kR0Vec; j++) {
+          if ((tied >> j) & 1u) {
+            hpos[o] = static_cast<uint32_t>(k0 + j);
+            hkey[o] = me[t][j];
+            o++;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t q = lane; q < total; q += kWave) {
+          gdepth[hpos[q]] = static_cast<uint32_t>(count_key_symbols(wide(hkey[q]), kKeyBits, s_fl, uniform_bits));
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (k0 + kR0Vec <= n) {
+        uint4 *hdst = reinterpret_cast<uint4 *>(hd + k0), *ldst = reinterpret_cast<uint4 *>(lcp + k0);
+#pragma unroll
+        for (int q = 0; q < kR0Vec / 4; q++) {
+          hdst[q] = make_uint4(hv[4 * q], hv[4 * q + 1], hv[4 * q + 2], hv[4 * q + 3]);
+          if (LCP) {
+            ldst[q] = make_uint4(static_cast<uint32_t>(lv[4 * q]), static_cast<uint32_t>(lv[4 * q + 1]),
+                                 static_cast<uint32_t>(lv[4 * q + 2]), static_cast<uint32_t>(lv[4 * q + 3]));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < kR0Vec; j++) {
+          if (k0 + j < n) {
+            hd[k0 + j] = hv[j];
+            if (LCP && k0 + j + 1 < n) lcp[k0 + j] = lv[j];
+          }
+        }
+      }
+      if (sa_dbg) {
+#pragma unroll
+        for (int j = 0; j < kR0Vec; j++) {
+          if (k0 + j < n) sa_dbg[k0 + j] = vals[k0 + j];
+        }
+      }
+      // wave carry for the next step: the last head of the highest lane that has one
+      if (bh) {
+        const int hl = 63 - __clzll(static_cast<long long>(bh));
+        carry = static_cast<size_t>(__shfl(my_last_pos, hl, kWave));
+      }
+      prev_last = __shfl(me[t][kR0Vec - 1], kWave - 1, kWave);
     }
-    // wave carry for the next step: the last head of the highest lane that has one
-    if (bh) {
-      const int hl = 63 - __clzll(static_cast<long long>(bh));
-      carry = static_cast<size_t>(__shfl(my_last_pos, hl, kWave));
-    }
-    prev_last = __shfl(me[t][kR0Vec - 1], kWave - 1, kWave);
   }
 }
 
