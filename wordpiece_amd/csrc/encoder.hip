@@ -151,6 +151,7 @@ struct Context {
   uint32_t *d_used = nullptr, *d_lut = nullptr, *d_scan_tmp = nullptr;  // code point tables
   uint32_t *d_scalars = nullptr;                                         // kScalars words of device scalars
   uint8_t *d_code = nullptr;     // symbol code tables: cw u16[256] | len u8[256] | bmask u16[4096]
+  uint8_t *h_code = nullptr;     // pinned staging of the same (the upload needs no host wait: every encode ends with one)
   uint32_t *d_symhist = nullptr;  // 256 counters
   uint32_t *h_scalars = nullptr;                                         // pinned mirror
   RadixStats rstats;
@@ -210,6 +211,7 @@ static void destroy_context(Context *c) {
     if (p) (void)hipFree(p);
   }
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+  if (c->h_code) (void)hipHostFree(c->h_code);
   c->text_buf.release();
   c->a_buf.release();
   c->b_buf.release();
@@ -330,6 +332,7 @@ static std::unique_ptr<Context> make_context(const wp_vocab *v, int device) {
   WP_HIP(hipMalloc(&c->d_scan_tmp, sizeof(uint32_t) * (cdiv(kCpTableSize, kScanTile) + 8)));
   WP_HIP(hipMalloc(&c->d_scalars, sizeof(uint32_t) * kScalars));
   WP_HIP(hipMalloc(&c->d_code, 512 + 256 + kDecodeTableBytes));
+  WP_HIP(hipHostMalloc(&c->h_code, 512 + 256 + kDecodeTableBytes));
   WP_HIP(hipMalloc(&c->d_symhist, sizeof(uint32_t) * 256));
   WP_HIP(hipHostMalloc(&c->h_scalars, sizeof(uint32_t) * kScalars));
   for (auto &e : c->ev) WP_HIP(hipEventCreate(&e));
@@ -630,12 +633,12 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   DevCode dcode{reinterpret_cast<const uint16_t *>(c->d_code), c->d_code + 512, c->d_code + 768,
                 code.uniform_bits ? code.uniform_bits : -code.lo_bits};
   if (!code.uniform_bits) {
-    std::vector<uint8_t> blob(512 + 256 + kDecodeTableBytes, 0);
-    std::memcpy(blob.data(), code.cw.data(), code.cw.size() * sizeof(uint16_t));
-    std::memcpy(blob.data() + 512, code.len.data(), code.len.size());
-    std::memcpy(blob.data() + 768, code.bmask.data(), kDecodeTableBytes);
-    WP_HIP(hipMemcpyAsync(c->d_code, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
-    WP_HIP(hipStreamSynchronize(st));  // blob is a stack object
+    const size_t blob_bytes = 512 + 256 + kDecodeTableBytes;
+    std::memset(c->h_code, 0, blob_bytes);
+    std::memcpy(c->h_code, code.cw.data(), code.cw.size() * sizeof(uint16_t));
+    std::memcpy(c->h_code + 512, code.len.data(), code.len.size());
+    std::memcpy(c->h_code + 768, code.bmask.data(), kDecodeTableBytes);
+    WP_HIP(hipMemcpyAsync(c->d_code, c->h_code, blob_bytes, hipMemcpyHostToDevice, st));
   }
   S.symbols_per_key = static_cast<int32_t>(kKeyBits / std::max(1.0, code.avg_bits));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(build_keys0_kernel<SymT>), dim3(cdiv(n, kKeyTile)), dim3(kBlock), 0, st, d_sym,

@@ -24,51 +24,43 @@ namespace wp {
 
 constexpr uint32_t kClaimEmpty = 0xffffffffu;
 
-// first kKeyBits bits of the code stream of token symbols cps[0..len) (code points -> dense symbols
-// through lut), left aligned; bits_out = bits of the stream inside the key (<= kKeyBits); returns true
-// if the stream is longer than the key (a "long" token)
-__device__ inline bool token_key(const uint32_t *__restrict__ cps, uint32_t len, const uint32_t *__restrict__ lut_excl,
-                                 const DevCode &code, uint64_t &key_out, int &bits_out) {
+// First kKeyBits bits of the code stream of token symbols cps[0..len) (code points -> dense symbols through lut),
+// left aligned; bits_out = bits of the stream inside the key (<= kKeyBits); returns true if the stream is longer
+// than the key (a "long" token).  By a whole wave: lane j takes symbol j (a key holds at most kKeyBits symbols), the codeword ends come
+// from one wave scan and the key from an OR across the lanes — three dependent loads instead of three per symbol
+// (the per-token kernels are chains of dependent loads).  whole_out: codewords that lie in the key completely
+// (= count_key_symbols of the key).  All 64 lanes must be active; every lane gets the same results.
+__device__ inline bool wave_token_key(const uint32_t *__restrict__ cps, uint32_t len, const uint32_t *__restrict__ lut_excl,
+                                      const DevCode &code, uint64_t &key_out, int &bits_out, uint32_t &whole_out) {
   const int ub = code.uniform_bits > 0 ? code.uniform_bits : 0;
   const int lo = code.uniform_bits < 0 ? -code.uniform_bits : 0;
   const uint32_t lomask = (1u << lo) - 1u;
-  uint64_t key = 0;
-  int used = 0;
-  bool overflow = false;
-  for (uint32_t j = 0; j < len; j++) {
-    const uint32_t sv = lut_excl[cps[j]] + 1u;
-    int l;
-    uint32_t c;
+  const uint32_t lane = static_cast<uint32_t>(lane_id());
+  uint32_t l = 0;
+  uint64_t c = 0;
+  if (lane < len) {
+    const uint32_t sv = lut_excl[cps[lane]] + 1u;
     if (ub) {
-      l = ub;
+      l = static_cast<uint32_t>(ub);
       c = sv;
     } else {
       const uint32_t hi = sv >> lo;
-      l = static_cast<int>(code.len[hi]) + lo;
-      c = (static_cast<uint32_t>(code.cw[hi]) << lo) | (sv & lomask);
+      l = static_cast<uint32_t>(code.len[hi]) + static_cast<uint32_t>(lo);
+      c = (static_cast<uint64_t>(code.cw[hi]) << lo) | (sv & lomask);
     }
-    if (used + l > kKeyBits) {
-      const int take = kKeyBits - used;
-      if (take > 0) key = (key << take) | (c >> (l - take));
-      used = kKeyBits;
-      overflow = true;
-      break;
-    }
-    key = (key << l) | c;
-    used += l;
   }
-  key_out = key << (kKeyBits - used);
-  bits_out = used;
-  return overflow;
-}
-
-__device__ __forceinline__ size_t key_lower_bound(const Key0 *__restrict__ keys, size_t n, uint64_t key) {
-  size_t lo = 0, hi = n;
-  while (lo < hi) {
-    const size_t md = (lo + hi) >> 1;
-    if (static_cast<uint64_t>(keys[md]) < key) lo = md + 1; else hi = md;
+  const uint32_t end = wave_incl_sum(l), start = end - l;  // bit range of the lane's codeword in the stream
+  uint64_t part = 0;
+  if (l && start < static_cast<uint32_t>(kKeyBits)) {
+    part = end <= static_cast<uint32_t>(kKeyBits) ? c << (kKeyBits - end) : c >> (end - kKeyBits);
   }
-  return lo;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) part |= __shfl_xor(part, d, kWave);
+  const uint32_t total = __shfl(end, kWave - 1, kWave);  // bits of the first min(len, 64) symbols
+  whole_out = static_cast<uint32_t>(__popcll(__ballot(l && end <= static_cast<uint32_t>(kKeyBits))));
+  key_out = part;
+  bits_out = static_cast<int>(total < static_cast<uint32_t>(kKeyBits) ? total : static_cast<uint32_t>(kKeyBits));
+  return total > static_cast<uint32_t>(kKeyBits) || len > static_cast<uint32_t>(kWave);
 }
 
 // suffix at text position v against the token (dense symbols through lut): -1 / +1 = the suffix sorts
@@ -119,7 +111,8 @@ __global__ __launch_bounds__(kBlock) void need_groups_kernel(const Key0 *__restr
   int bits = 0;
   const uint32_t len = tok_info[m] & 0x0fffffffu;
   const uint32_t *cps = vocab_cps + tok_start[m];
-  const bool is_long = token_key(cps, len, lut_excl, code, key, bits);  // wave-uniform
+  uint32_t whole = 0;
+  const bool is_long = wave_token_key(cps, len, lut_excl, code, key, bits, whole);  // wave-uniform
   if (!is_long) {
     if (!rng_lo) return;
     // (the whole wave searches: wave_key_lower_bound)
@@ -171,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void need_groups_kernel(const Key0 *__restr
       h = (h + 1) & claim_mask;
     }
     if (won) {
-      depth = static_cast<uint32_t>(count_key_symbols(key, kKeyBits, code.first_len, code.uniform_bits));
+      depth = whole;  // (= count_key_symbols(key, kKeyBits, ...): the codewords that lie in the key completely)
       if (depth < out.need_depth) {
         got = atomicAdd(out.totals, (1ull << 32) | static_cast<unsigned long long>(last - first));
       }
@@ -191,9 +184,32 @@ __global__ __launch_bounds__(kBlock) void needed_fill_kernel(NeededList out, con
                                                              size_t n) {
   const uint32_t *t32 = reinterpret_cast<const uint32_t *>(out.totals);
   const uint32_t n_act = t32[0], n_groups = t32[1];
-  for (size_t p = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; p < n_act;
-       p += static_cast<size_t>(gridDim.x) * kBlock) {
-    uint32_t lo = 0, hi = n_groups;  // last group with ghead[g] <= p
+  // a wave takes 64 consecutive list positions at a time: a 64-way search finds the group of the first one (3
+  // dependent loads for 2e5 groups), the others lie at most 63 groups further on (a group has at least one entry)
+  // — a binary search over all groups per entry made this kernel a chain of ~14 dependent loads
+  const int lane = lane_id();
+  for (size_t p0 = (static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) & ~static_cast<size_t>(kWave - 1); p0 < n_act;
+       p0 += static_cast<size_t>(gridDim.x) * kBlock) {
+    const size_t p = p0 + lane;
+    // first group whose successor starts behind p0, i.e. the last g with ghead[g] <= p0
+    uint32_t a = 0, b = n_groups - 1;  // answer in [a, b]
+    while (a < b) {
+      const uint32_t st = (b - a) / kWave + 1;
+      const uint32_t idx = a + static_cast<uint32_t>(lane) * st;
+      const bool gt = idx < b ? out.ghead[idx + 1] > p0 : true;  // (group idx ends behind p0)
+      const uint64_t mm = __ballot(gt);
+      if (!mm) {
+        a += (kWave - 1) * st + 1;
+        continue;
+      }
+      const uint32_t t = static_cast<uint32_t>(__ffsll(static_cast<long long>(mm)) - 1);
+      const uint32_t first = a + t * st;
+      if (t) a += (t - 1) * st + 1;
+      b = first < b ? first : b;
+      if (!t) b = a;
+    }
+    if (p >= n_act) continue;
+    uint32_t lo = a, hi = min(n_groups, a + static_cast<uint32_t>(kWave));  // last group in [lo, hi) with ghead[g] <= p
     while (hi - lo > 1) {
       const uint32_t md = (lo + hi) >> 1;
       if (out.ghead[md] <= p) lo = md; else hi = md;
