@@ -35,8 +35,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/
 # one radix pass reads and writes a (key, index) record: 12 bytes with a 64-bit key (round 1 of this
 # build), 8 bytes with the 32-bit round-0 keys of this round (wp_stats.key_bits); radix_bytes() below
 # SA/LCP stage, algorithmic bytes per symbol besides the radix passes:
-SPLIT_BYTES = 12       # round 0 after the sort (round0_rank_kernel): keys 4 read, rank 4 + LCP 4 written
-RANK_STORE_BYTES = 32  # destination partition (4 read; 8 read + 8 written) + scatter (8 read, 4 written)
+SPLIT_BYTES = 12       # round 0 after the sort (round0_rank_kernel): keys 4 read, rank 4 + LCP 4 written (no LCP array
+                       # in the text-only layout, where nothing reads it: 8)
+RANK_STORE_BYTES = 12  # window store: (destination, rank) 8 read, rank 4 written; the one or two partition passes in
+                       # front of it are full-size launches of the radix scatter (16 B per element, counted there)
 ROUND_BYTES = 110      # rounds >= 1, per list entry: LDS sort 28 + split 50 + rank store 32
 
 _DevView = W.DeviceIds  # zero-copy torch view of a device buffer owned by the library
@@ -222,7 +224,7 @@ def main():
         RADIX_BYTES_PER_ELEM = 2 * (key_bytes + 4)
         scatter_name = "radix_scatter_kernel<%s> (full-size tiles: the %d passes of the round-0 suffix sort over %d-bit keys%s; %d-byte records)" % (
             "uint32, 16" if key_bytes == 4 else "uint64, 24", (st["key_bits"] + 7) // 8, st["key_bits"],
-            " and the destination partition of the rank store" if key_bytes == 4 else "", key_bytes + 4)
+            " and the destination-partition passes of the round-0 rank store" if key_bytes == 4 else "", key_bytes + 4)
         ms_per_step = dt_max / args.steps * 1e3
         value = total_bytes / 1e6 / (dt_max / args.steps)
         # dominant kernel: the radix scatter pass.  Algorithmic bytes per launch = the (key, index) record read and
@@ -251,7 +253,7 @@ def main():
                        "sorted_depth": st["sorted_depth"], "symbol_bits": st["symbol_bits"],
                        "symbols_per_key": st["symbols_per_key"], "key_bits": st["key_bits"], "active_per_round": st["active_per_round"],
                        "needed_after_round0": st["needed_after_round0"],
-                       "radix_launches_per_step": radix_launches // steps,
+                       "radix_launches_per_step": radix_launches // steps, "staged_emit": st["staged_emit"],
                        "id_gather": ("%s: exact-size receives on rank 0" % ("rccl" if backend == "nccl" else backend)) if distributed
                        else "none (single GPU)"},
             "roofline": {"bound": "hbm", "kernel": scatter_name, "achieved": round(achieved, 1),
@@ -265,15 +267,15 @@ def main():
         n_sym, act = st["n_total"], st["active_per_round"]
         passes = radix_elems / steps
         dig = (2 * digit_bytes / steps + n_sym) if digit_bytes else key_bytes * passes  # written + read (+ the key builder's bytes), or the key re-read
-        store = RANK_STORE_BYTES - (16 if key_bytes == 4 else 0)  # (the partition scatter's 16 B are inside `passes` then)
-        sa_bytes = RADIX_BYTES_PER_ELEM * passes - 4 * n_sym + dig + (SPLIT_BYTES + store) * n_sym + ROUND_BYTES * sum(act[1:])
+        split = SPLIT_BYTES - (4 if st["vocab_in_s"] == 0 else 0)
+        sa_bytes = RADIX_BYTES_PER_ELEM * passes - 4 * n_sym + dig + (split + RANK_STORE_BYTES) * n_sym + ROUND_BYTES * sum(act[1:])
         sa_ms = stage_ms.get("ms_sa", 0.0) / steps
         if sa_ms > 0:
             out["sa_lcp_stage"] = {"algorithmic_bytes": int(sa_bytes), "ms": round(sa_ms, 3),
                                    "achieved": round(sa_bytes / 1e9 / (sa_ms / 1e3), 1), "unit": "GB/s",
                                    "frac": round(sa_bytes / 1e9 / (sa_ms / 1e3) / HBM_PEAK_GBPS, 4),
                                    "per_symbol": {"radix_pass": RADIX_BYTES_PER_ELEM, "digit_bytes_total": round(dig / n_sym, 2),
-                                                  "split": SPLIT_BYTES, "rank_store": RANK_STORE_BYTES, "round_entry": ROUND_BYTES}}
+                                                  "split": split, "rank_store_window": RANK_STORE_BYTES, "round_entry": ROUND_BYTES}}
         if world == 1 and not args.no_extras:
             # SURVEY 8(d)'s metric proper: host-resident text -> host-resident ids (pageable source, ids into a pinned
             # block of the library's pool), wall clock around wp_linear_encode

@@ -493,7 +493,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   SymT *d_sym = nullptr;
   uint8_t *DG0 = nullptr, *DG1 = nullptr, *d_rng_long = nullptr;
   uint32_t *d_rng_lo = nullptr, *d_rng_hi = nullptr;
-  uint32_t *d_claim = nullptr;
+  uint32_t *d_claim = nullptr, *d_claim_need = nullptr, *d_gclaim = nullptr, *d_gneed0 = nullptr, *d_gneed1 = nullptr;
   size_t claim_size = 1024;  // hash table of claimed key ranges (prune.h): a power of two >= 2 M
   while (claim_size < 2 * static_cast<size_t>(std::max(M, 1))) claim_size *= 2;
   uint64_t *K0 = nullptr, *K1 = nullptr;
@@ -523,6 +523,10 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     DG0 = use_digit_bytes ? ar.take<uint8_t>(n + 64) : nullptr;
     DG1 = use_digit_bytes ? ar.take<uint8_t>(n + 64) : nullptr;
     d_claim = ar.take<uint32_t>(claim_size);
+    d_claim_need = ar.take<uint32_t>(claim_size);
+    d_gclaim = ar.take<uint32_t>(M + 1);
+    d_gneed0 = ar.take<uint32_t>(n / 2 + 4);
+    d_gneed1 = ar.take<uint32_t>(n / 2 + 4);
     V0 = ar.take<uint32_t>(n);
     V1 = ar.take<uint32_t>(n);
     AS0 = ar.take<uint32_t>(n);
@@ -650,7 +654,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   // round 0 only keeps the tied groups that carry the key of a long eligible token (prune.h)
   static const bool env_no_prune = env_flag("WP_NO_PRUNE");
   const bool prune = !full && !env_no_prune && (M > 0 || text_only);
-  const DepthRule rule{need_depth, full ? 1 : 0};
+  const DepthRule rule{need_depth, full ? 1 : 0, nullptr, nullptr};
   // after every rerank: classify the new groups (large ones take the global path next round)
   // (runs on the side stream, next to the rank scatter)
   auto classify_groups = [&](size_t list_len) {
@@ -773,7 +777,8 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       WP_HIP(hipMemsetAsync(d_claim, 0xff, claim_size * sizeof(uint32_t), st2));
       NeededList nl{slots, other_vals, AG, adep, d_ghead, d_large_id, d_large_off,  // (the large-group tables are free until the classification)
                     reinterpret_cast<unsigned long long *>(c->d_scalars + 4),
-                    text_only && !v->keep_debug ? d_sa : nullptr, need_depth};
+                    text_only && !v->keep_debug ? d_sa : nullptr, need_depth, d_claim_need, d_gclaim, d_gneed0};
+      WP_HIP(hipMemsetAsync(d_claim_need, 0, claim_size * sizeof(uint32_t), st2));
       if (M > 0) {  // (no eligible token at all: every tied group retires)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(need_groups_kernel<SymT>), dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)),
                            dim3(kBlock), 0, st2, keys, vals, n, d_sym, c->d_stream, c->d_elig_start, c->d_elig_info, M,
@@ -781,7 +786,10 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
                            text_only ? d_rng_lo : nullptr, d_rng_hi, d_rng_long);
       }
       hipLaunchKernelGGL(needed_list_close_kernel, dim3(1), dim3(1), 0, st2, c->d_scalars + 4, d_ghead);
-      if (M > 0) hipLaunchKernelGGL(needed_fill_kernel, dim3(1024), dim3(kBlock), 0, st2, nl, vals, n);
+      if (M > 0) {
+        hipLaunchKernelGGL(needed_need_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st2, nl);  // (a needed group per token at most)
+        hipLaunchKernelGGL(needed_fill_kernel, dim3(1024), dim3(kBlock), 0, st2, nl, vals, n);
+      }
       if (d_lcp) {
         hipLaunchKernelGGL(round0_rank_kernel<true>, dim3(cdiv(n, kR0Tile)), dim3(kBlock), 0, st, keys, vals, n,
                            dcode.first_len, dcode.uniform_bits, (v->keep_debug || v->lcp_kasai) ? d_sa : nullptr, hd, d_lcp,
@@ -862,7 +870,17 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   }
   int rounds = 1;
   S.active_per_round[0] = static_cast<int64_t>(n);
+  // behind a pruned round 0 every group carries the depth its own tokens need (DepthRule, prune.h)
+  static const bool env_global_need = env_flag("WP_GLOBAL_NEED");
+  uint32_t *gneed_cur = d_gneed0, *gneed_nxt = d_gneed1;
+  const bool group_need = prune && M > 0 && !env_global_need;
   while (n_act > 0) {
+    DepthRule rrule = rule;
+    if (group_need) {
+      rrule.gneed_in = gneed_cur;
+      rrule.gneed_out = gneed_nxt;
+      std::swap(gneed_cur, gneed_nxt);
+    }
     // A round adds to a group's depth the depth of the group its second keys point into: that doubles the
     // depth while those groups are refined too (full depth: 31 rounds for 2^31 symbols), and adds at least the
     // depth of a round-0 group — one symbol or more — when they retired in round 0 (depth-capped mode: a
@@ -896,20 +914,20 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       lb.ticket = reinterpret_cast<uint32_t *>(lb.wb + tiles);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_fused_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
                          svals, slots, adep, n_act, tiles, lb, d_sym, d_rank, d_gdepth, n, dcode.first_len,
-                         dcode.uniform_bits, rule, d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead,
+                         dcode.uniform_bits, rrule, d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead,
                          d_gdepth, d_tdep, c->d_scalars + 4);
       hipLaunchKernelGGL(gdepth_store_kernel, dim3(cdiv(n_act, kBlock)), dim3(kBlock), 0, st, d_tdep, slots, n_act,
                          d_gdepth);
     } else {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<false>), dim3(tiles), dim3(kBlock), 0, st, skeys, svals,
-                         n_act, adep, d_rank, d_gdepth, n, dcode.first_len, dcode.uniform_bits, rule, d_tdep, d_agg);
+                         n_act, adep, d_rank, d_gdepth, n, dcode.first_len, dcode.uniform_bits, rrule, d_tdep, d_agg);
       hipLaunchKernelGGL(rerank_chunk_kernel, dim3(cdiv(tiles, kRrChunk)), dim3(kBlock), 0, st, d_agg, tiles,
                          d_chunk_agg);
       hipLaunchKernelGGL(rerank_prefix_kernel, dim3(cdiv(tiles, kRrChunk)), dim3(kBlock), 0, st, d_agg, d_chunk_agg,
                          tiles);
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st, skeys,
                          svals, slots, adep, d_tdep, n_act, d_agg, d_sym, n, dcode.first_len,
-                         dcode.uniform_bits, rule, d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead,
+                         dcode.uniform_bits, rrule, d_sa, hd, d_lcp, other_slots, nvals, AG, other_dep, d_ghead,
                          d_gdepth, c->d_scalars + 4);
     }
     fork();

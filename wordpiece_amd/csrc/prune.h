@@ -90,6 +90,10 @@ struct NeededList {
   unsigned long long *totals;  // low word: list entries, high word: groups (one atomic allocates both)
   uint32_t *sa;                // != nullptr: slot -> suffix for the slots of needed groups (text-only layout)
   uint32_t need_depth;         // a group whose depth reaches this needs no refinement (depth cap)
+  // depth each needed group has to reach: 1 + the longest eligible token that carries its key (all of them meet
+  // in the group's slot of the claim table: claim_need, by atomic max); gclaim: that slot, gneed: the result per
+  // group (needed_need_kernel) — what DepthRule::gneed_in starts from
+  uint32_t *claim_need, *gclaim, *gneed;
 };
 
 template <typename SymT>
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void need_groups_kernel(const Key0 *__restr
   }
   // several tokens share a key (all long prefixes of one word): the first to claim the range appends it
   unsigned long long got = ~0ull;
-  uint32_t depth = 0;
+  uint32_t depth = 0, claim_slot = 0;
   if (lane == 0) {
     uint32_t h = (static_cast<uint32_t>(first) * 2654435761u) & claim_mask;
     bool won = false;
@@ -163,6 +167,8 @@ __global__ __launch_bounds__(kBlock) void need_groups_kernel(const Key0 *__restr
       if (old == static_cast<uint32_t>(first)) break;
       h = (h + 1) & claim_mask;
     }
+    atomicMax(&out.claim_need[h], min(len, out.need_depth - 1u) + 1u);
+    claim_slot = h;
     if (won) {
       depth = whole;  // (= count_key_symbols(key, kKeyBits, ...): the codewords that lie in the key completely)
       if (depth < out.need_depth) {
@@ -175,7 +181,13 @@ __global__ __launch_bounds__(kBlock) void need_groups_kernel(const Key0 *__restr
     out.ghead[g] = static_cast<uint32_t>(got);
     out.gfirst[g] = static_cast<uint32_t>(first);
     out.gdepth[g] = depth;
+    out.gclaim[g] = claim_slot;
   }
+}
+
+__global__ __launch_bounds__(kBlock) void needed_need_kernel(NeededList out) {
+  const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+  if (g < reinterpret_cast<const uint32_t *>(out.totals)[1]) out.gneed[g] = out.claim_need[out.gclaim[g]];
 }
 
 // entries of the needed groups: list position p belongs to the group g with ghead[g] <= p < ghead[g+1]

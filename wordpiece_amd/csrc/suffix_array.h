@@ -37,9 +37,19 @@ struct RerankAgg {
 struct DepthRule {
   uint32_t need;  // a tied group retires once its depth reaches this (depth-capped mode)
   int full;       // 1: only singletons retire (true suffix array)
+  // Rounds >= 1 behind a pruned round 0: every group of the list carries the depth ITS tokens need (the longest
+  // eligible token that carries the round-0 key, + 1; prune.h) instead of the longest token of the whole vocabulary,
+  // handed down from a group to the subgroups it splits into.  gneed_in: by the group ids of the list being split
+  // (nullptr: `need` for everyone), gneed_out: by the new group ids.
+  const uint32_t *gneed_in;
+  uint32_t *gneed_out;
 };
 
-__device__ __forceinline__ bool rr_stays_active(const DepthRule &rule, uint32_t nd) { return rule.full || nd < rule.need; }
+// old_gid: group of the entry in the list being split (high word of its key in rounds >= 1)
+__device__ __forceinline__ bool rr_stays_active(const DepthRule &rule, uint32_t nd, uint32_t old_gid) {
+  if (rule.full) return true;
+  return nd < (rule.gneed_in ? rule.gneed_in[old_gid] : rule.need);
+}
 
 __device__ __forceinline__ void rr_flags(const uint64_t *__restrict__ keys, size_t m, size_t k, bool &flag,
                                          bool &single) {
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
           nd = min(d + dj, 0x7fffffffu);
         }
         tdep[k] = nd;
-        act = rr_stays_active(rule, nd);
+        act = rr_stays_active(rule, nd, ROUND0 ? 0u : static_cast<uint32_t>(keys[k] >> 32));
       }
     }
     const uint64_t bf = __ballot(f), ba = __ballot(act), bh = __ballot(f && act);
@@ -359,7 +369,7 @@ __device__ __forceinline__ void rr_first_half(RrTile &T, const uint64_t *__restr
           const uint32_t dj = r2 ? gdepth_in[r2 - 1u] : 0u;
           nd = min(d + dj, 0x7fffffffu);
         }
-        act = rr_stays_active(rule, nd);
+        act = rr_stays_active(rule, nd, ROUND0 ? 0u : static_cast<uint32_t>(me >> 32));
       }
       if (ROUND0) {
         nd = min(nd, 0xffffu);
@@ -395,7 +405,7 @@ __device__ __forceinline__ void rr_second_half(const RrTile &T, const uint64_t *
                                                uint32_t *__restrict__ nslots, uint32_t *__restrict__ nvals,
                                                uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep,
                                                uint32_t *__restrict__ ghead, uint32_t *__restrict__ gdepth,
-                                               uint32_t *__restrict__ gd) {
+                                               uint32_t *__restrict__ gd, const DepthRule &rule) {
   const int lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
   // rounds >= 1: does the group of the carried head continue the old group of the entry before it?
@@ -457,7 +467,10 @@ __device__ __forceinline__ void rr_second_half(const RrTile &T, const uint64_t *
         nvals[pos] = v;
         ngid[pos] = g;
         ndep[pos] = nd;
-        if (f) ghead[g] = pos;
+        if (f) {
+          ghead[g] = pos;
+          if (!ROUND0 && rule.gneed_in) rule.gneed_out[g] = rule.gneed_in[static_cast<uint32_t>(keys[k] >> 32)];
+        }
       }
     }
     ea += __popcll(ba);
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void rerank_apply_kernel(
     head1 = max(head1, s_last[i]);
   }
   rr_second_half<SymT, ROUND0>(T, keys, m, wave_base, ea, eh, head1, vals, slots, adep, sym, n, s_fl, uniform_bits, sa,
-                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, nullptr);
+                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, nullptr, rule);
 }
 
 // full-depth mode with 32-bit round-0 keys: the count / prefix / apply kernels below take 64-bit keys
@@ -840,7 +853,7 @@ __global__ __launch_bounds__(kBlock) void rerank_fused_kernel(
     head1 = max(head1, s_last[i]);
   }
   rr_second_half<SymT, ROUND0>(T, keys, m, wave_base, ea, eh, head1, vals, slots, adep, sym, n, s_fl, uniform_bits, sa,
-                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, ROUND0 ? nullptr : gd);
+                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, ROUND0 ? nullptr : gd, rule);
 }
 
 __global__ __launch_bounds__(kBlock) void gdepth_store_kernel(const uint32_t *__restrict__ gd,
