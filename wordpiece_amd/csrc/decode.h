@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
   constexpr int kSymSlots = kKeyTile + kKeyHalo;
   __shared__ uint32_t ss[kSymSlots + kSymSlots / 8 + 1];
   __shared__ uint32_t stab[256];  // (len << 16) | codeword
-  __shared__ uint64_t skey[kKeyTile + kKeyTile / 8 + 1];
+  __shared__ Key0 skey[kKeyTile + kKeyTile / 8 + 1];  // (keys of up to 32 bits: half the LDS, 8 instead of 5 workgroups per CU)
   const size_t base = static_cast<size_t>(blockIdx.x) * kKeyTile;
   for (int k = threadIdx.x; k < kSymSlots; k += kBlock) {
     size_t i = base + k;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
       key = (key << take) | (c >> (l - take));
       used += take;
     }
-    skey[key_pad(p0 + kKeyItems - 1)] = key;
+    skey[key_pad(p0 + kKeyItems - 1)] = static_cast<Key0>(key);
 #pragma unroll
     for (int j = kKeyItems - 2; j >= 0; j--) {
       const uint32_t sv = ss[key_pad(p0 + j)];
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
       const int l = ub ? ub : static_cast<int>(e >> 16) + lo;
       const uint64_t c = ub ? sv : (((e & 0xffffu) << lo) | (sv & lomask));
       key = (c << (kKeyBits - l)) | (key >> l);
-      skey[key_pad(p0 + j)] = key;
+      skey[key_pad(p0 + j)] = static_cast<Key0>(key);
     }
   }
   __syncthreads();
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
     const int li = j * kBlock + threadIdx.x;
     const size_t i = base + li;
     if (i < n) {
-      const uint64_t k = skey[key_pad(li)];
-      keys[i] = static_cast<Key0>(k);  // (the values, 0..n-1, are made up by the first radix pass)
+      const Key0 k = skey[key_pad(li)];
+      keys[i] = k;  // (the values, 0..n-1, are made up by the first radix pass)
       if (dig0) dig0[i] = static_cast<uint8_t>(k);  // first radix digit: that pass's histogram reads 1 byte per key
     }
   }

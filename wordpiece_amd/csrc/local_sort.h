@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void group_stats_kernel(const uint32_t *__r
 // entries of large groups -> (key, val, list position) in the large list; key = dense large-group
 // number << rbits | second key.  A wave owns kLxSpan consecutive positions of the large list: one
 // search for its first group, then it only moves forward (large groups are long runs).
-constexpr int kLxSpan = 256;  // (2048: 32 dependent gather rounds per wave, 94 us for 5e5 entries)
+constexpr int kLxSpan = 64;  // (2048: 32 dependent gather rounds per wave, 94 us for 5e5 entries; 256: 69 us)
 __global__ __launch_bounds__(kBlock) void large_extract_kernel(
     const uint32_t *__restrict__ aval, const uint32_t *__restrict__ adep, const uint32_t *__restrict__ lg_head,
     const uint32_t *__restrict__ lg_off, uint32_t n_lg, size_t n_large, const RankEntry *__restrict__ rank, size_t n,
