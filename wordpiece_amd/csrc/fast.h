@@ -90,32 +90,45 @@ __device__ __forceinline__ int32_t f_match(const FastArgs &a, size_t p) {
   return best;
 }
 
+// one token (or the [UNK] of its word) of a lane's walk; true when the lane's stretch of text ends
 template <typename Out>
-__device__ inline void fast_walk_from(const FastArgs &a, size_t p, Out &o) {
+__device__ __forceinline__ bool fast_walk_step(const FastArgs &a, WalkState &s, Out &o) {
   const size_t end = a.n_text;
-  size_t since = p;  // start of the tokens counted by tokens_since_prefix
-  o.word_start();
-  while (p < end) {
-    const int32_t id = f_match(a, p);
-    if (id != -1) {
-      o.push(p, id);
-      p += static_cast<size_t>(a.tok_len[id]);
-      if (p < end && f_word_prefix(a, p)) {  // fast.cpp:90-92
-        since = p;
-        o.word_start();
-      }
-    } else {  // fast.cpp:80-89: roll the word's tokens back, [UNK], skip the rest of the word
-      o.rollback(since, p);
-      o.push(p, a.unk_id);
-      p += f_word_len(a, p);
-      while (p < end && !f_word_prefix(a, p)) ++p;
-      since = p;
+  size_t p = s.p;
+  const int32_t id = f_match(a, p);
+  if (id != -1) {
+    o.push(p, id);
+    p += static_cast<size_t>(a.tok_len[id]);
+    if (p < end && f_word_prefix(a, p)) {  // fast.cpp:90-92
+      s.since = p;
       o.word_start();
     }
-    // behind a space the next non-space position is an anchor of its own (fast.cpp:94-96 skips the run)
-    if (p >= end || (a.cls[p] & kClsSpace) || f_anchor(a, p)) return;
+  } else {  // fast.cpp:80-89: roll the word's tokens back, [UNK], skip the rest of the word
+    o.rollback(s.since, p);
+    o.push(p, a.unk_id);
+    p += f_word_len(a, p);
+    while (p < end && !f_word_prefix(a, p)) ++p;
+    s.since = p;
+    o.word_start();
+  }
+  s.p = p;
+  // behind a space the next non-space position is an anchor of its own (fast.cpp:94-96 skips the run)
+  return p >= end || (a.cls[p] & kClsSpace) || f_anchor(a, p);
+}
+
+template <typename Out>
+__device__ inline void fast_walk_from(const FastArgs &a, size_t p, Out &o) {
+  WalkState s{p, p};
+  o.word_start();
+  while (s.p < a.n_text) {
+    if (fast_walk_step(a, s, o)) return;
   }
 }
+
+struct FastStep {
+  using State = WalkState;
+  __device__ static __forceinline__ bool step(const FastArgs &a, WalkState &s, StagedOut &o) { return fast_walk_step(a, s, o); }
+};
 
 // 16 class bytes per lane -> anchors as a 16-bit mask (same layout as anchor_mask16 of walk.h)
 __device__ __forceinline__ uint32_t fast_anchor_mask16(const uint8_t *__restrict__ cls, size_t n, size_t i) {
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void fast_walk_staged_kernel(FastArgs a, co
   const size_t na = min(cap, static_cast<size_t>(*n_anchors_dev));
   const size_t k0 = static_cast<size_t>(blockIdx.x) * kBlock;
   const size_t base = k0 < na ? anchors[k0] : 0;
-  StagedOut o{stage + threadIdx.x, a.emit, 0, 0};
+  StagedOut o{stage + threadIdx.x, a.emit, 0, 0, kBlock};
   if (k < na) {
     const uint32_t start = anchors[k];
     o.spill = a.emit + start;

@@ -72,12 +72,13 @@ struct SparseOut {
 };
 
 struct StagedOut {
-  int32_t *stage;  // LDS: this lane's column, stride kBlock
+  int32_t *stage;  // LDS: the column of this lane (or of the word the lane is on), rows `stride` apart
   int32_t *spill;  // emit + p0
   uint32_t c = 0, mark = 0;
+  uint32_t stride = kBlock;
   __device__ __forceinline__ void push(size_t, int32_t id) {
     if (c < static_cast<uint32_t>(kStageIds)) {
-      stage[c * kBlock] = id;
+      stage[c * stride] = id;
     } else {
       spill[c] = id;
     }
@@ -86,7 +87,7 @@ struct StagedOut {
   __device__ __forceinline__ void word_start() { mark = c; }
   __device__ __forceinline__ void rollback(size_t, size_t) { c = mark; }
   __device__ __forceinline__ int32_t get(uint32_t j) const {
-    return j < static_cast<uint32_t>(kStageIds) ? stage[j * kBlock] : spill[j];
+    return j < static_cast<uint32_t>(kStageIds) ? stage[j * stride] : spill[j];
   }
 };
 
@@ -99,60 +100,75 @@ __device__ __forceinline__ void flush_staged(const StagedOut &o, size_t base, in
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
 }
 
+// One step of a lane's walk: the token at s.p (or the [UNK] of its word) and what follows it up to the next
+// token start.  Returns true when the lane's stretch of text ends (end of text, or the next anchor).
+struct WalkState {
+  size_t p, since;  // position; start of the tokens counted by tokens_since_prefix
+};
+
+template <typename Out>
+__device__ __forceinline__ bool walk_step(const WalkArgs &a, WalkState &s, Out &o) {
+  const size_t end = a.n_text;
+  size_t p = s.p;
+  const bool prefix = w_word_prefix(a, p);
+  const uint32_t r = rank_of(a.rank[p]);
+  const int k = step_lookup(a.steps, r);
+  int32_t id = prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
+  if (!wp_in_bounds(id >= -1 && id < a.n_tokens, kSiteTokenId)) id = -1;
+  if (id != -1) {
+    o.push(p, id);
+    p += static_cast<size_t>(a.tok_len[id]);
+    if (p < end && w_word_prefix(a, p)) {
+      s.since = p;
+      o.word_start();
+    }
+  } else {
+    // roll back this word's tokens (linear.cpp:257-262), then [UNK]
+    o.rollback(s.since, p);
+    o.push(p, a.unk_id);
+    ++p;
+    while (p < end && !w_word_prefix(a, p)) {
+      ++p;
+      // coverage mode (texts with very long words): jump over whole tiles without a word-prefix
+      // position instead of stepping through them (a 10 M-char word otherwise costs a lane 2 s)
+      if (a.wp_from_tile && (p & (kReachTile - 1)) == 0 && p < end) {
+        p = min(static_cast<size_t>(a.wp_from_tile[p / kReachTile]), end);
+        break;
+      }
+    }
+    s.since = p;
+    o.word_start();
+  }
+  s.p = p;
+  if (p < end && w_space(a, p)) {
+    // class rule with only hard spacing chars: the first position behind the spaces is an anchor of
+    // its own, whatever it is — no need to step through the run (a megabyte of blanks otherwise
+    // stalls this lane for 0.2 s)
+    if (!a.aflags && a.all_hard) return true;
+    while (p < end && w_space(a, p)) {
+      ++p;
+      if (a.ns_from_tile && (p & (kReachTile - 1)) == 0 && p < end) {  // coverage mode: jump over blank tiles
+        p = min(static_cast<size_t>(a.ns_from_tile[p / kReachTile]), end);
+        break;
+      }
+    }
+    s.p = p;
+  }
+  if (p >= end || w_anchor(a, p)) return true;
+  // after skipped spaces p is a word-prefix position: counter restarts
+  if (w_word_prefix(a, p)) {
+    s.since = p;
+    o.word_start();
+  }
+  return false;
+}
+
 template <typename Out>
 __device__ inline void walk_from(const WalkArgs &a, size_t p, Out &o) {
-  const size_t end = a.n_text;
-  size_t since = p;  // start of the tokens counted by tokens_since_prefix
+  WalkState s{p, p};
   o.word_start();
-  while (p < end) {
-    const bool prefix = w_word_prefix(a, p);
-    const uint32_t r = rank_of(a.rank[p]);
-    const int k = step_lookup(a.steps, r);
-    int32_t id = prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
-    if (!wp_in_bounds(id >= -1 && id < a.n_tokens, kSiteTokenId)) id = -1;
-    if (id != -1) {
-      o.push(p, id);
-      p += static_cast<size_t>(a.tok_len[id]);
-      if (p < end && w_word_prefix(a, p)) {
-        since = p;
-        o.word_start();
-      }
-    } else {
-      // roll back this word's tokens (linear.cpp:257-262), then [UNK]
-      o.rollback(since, p);
-      o.push(p, a.unk_id);
-      ++p;
-      while (p < end && !w_word_prefix(a, p)) {
-        ++p;
-        // coverage mode (texts with very long words): jump over whole tiles without a word-prefix
-        // position instead of stepping through them (a 10 M-char word otherwise costs a lane 2 s)
-        if (a.wp_from_tile && (p & (kReachTile - 1)) == 0 && p < end) {
-          p = min(static_cast<size_t>(a.wp_from_tile[p / kReachTile]), end);
-          break;
-        }
-      }
-      since = p;
-      o.word_start();
-    }
-    if (p < end && w_space(a, p)) {
-      // class rule with only hard spacing chars: the first position behind the spaces is an anchor of
-      // its own, whatever it is — no need to step through the run (a megabyte of blanks otherwise
-      // stalls this lane for 0.2 s)
-      if (!a.aflags && a.all_hard) return;
-      while (p < end && w_space(a, p)) {
-        ++p;
-        if (a.ns_from_tile && (p & (kReachTile - 1)) == 0 && p < end) {  // coverage mode: jump over blank tiles
-          p = min(static_cast<size_t>(a.ns_from_tile[p / kReachTile]), end);
-          break;
-        }
-      }
-    }
-    if (p >= end || w_anchor(a, p)) return;
-    // after skipped spaces p is a word-prefix position: counter restarts
-    if (w_word_prefix(a, p)) {
-      since = p;
-      o.word_start();
-    }
+  while (s.p < a.n_text) {
+    if (walk_step(a, s, o)) return;
   }
 }
 
@@ -532,7 +548,7 @@ __global__ __launch_bounds__(kBlock) void walk_staged_kernel(WalkArgs a, const u
   const size_t na = min(cap, static_cast<size_t>(*n_anchors_dev));
   const size_t k0 = static_cast<size_t>(blockIdx.x) * kBlock;
   const size_t base = k0 < na ? anchors[k0] : 0;
-  StagedOut o{stage + threadIdx.x, a.emit, 0, 0};
+  StagedOut o{stage + threadIdx.x, a.emit, 0, 0, kBlock};
   if (k < na) {
     const uint32_t start = anchors[k];
     o.spill = a.emit + start;
@@ -541,14 +557,97 @@ __global__ __launch_bounds__(kBlock) void walk_staged_kernel(WalkArgs a, const u
   flush_staged(o, base, ctmp, blk_cnt, sm);
 }
 
-// ids[blk_off[b] ...] = the list of workgroup b
+// A lane per word makes every wave wait for its longest word: 1.2 tokens per word on average, 7 in the slowest of
+// 64 lanes, and a token is a chain of ~5 dependent loads (the kernel ran 84 % waiting, 20 us per wave).  Here a
+// wave owns kWbPerWave consecutive words and deals them out as lanes fall idle: every iteration each busy lane
+// takes ONE token step (Step::step), then the idle lanes pick the next words in order (ballot + prefix count,
+// no atomics).  Ids are staged per word (first kStageIds in LDS, the rest in the word's own stretch of emit[])
+// and leave as one list per workgroup, in word order, like walk_staged_kernel's.
+constexpr int kWbPerWave = 256;
+constexpr int kWbWords = kWbPerWave * (kBlock / kWave);
+struct LinearStep {
+  using State = WalkState;
+  __device__ static __forceinline__ bool step(const WalkArgs &a, WalkState &s, StagedOut &o) { return walk_step(a, s, o); }
+};
+
+template <typename Args, typename Step>
+__global__ __launch_bounds__(kBlock) void walk_balanced_kernel(Args a, const uint32_t *__restrict__ anchors,
+                                                               const uint32_t *__restrict__ n_anchors_dev, size_t cap,
+                                                               int32_t *__restrict__ ctmp, uint32_t *__restrict__ blk_cnt) {
+  __shared__ int32_t stage[kStageIds * kWbWords];
+  __shared__ uint32_t cnt[kWbWords];
+  __shared__ uint32_t sm[8];
+  const int lane = lane_id(), w = wave_id();
+  const size_t na = min(cap, static_cast<size_t>(*n_anchors_dev));
+  const size_t a0 = static_cast<size_t>(blockIdx.x) * kWbWords;
+  for (int q = threadIdx.x; q < kWbWords; q += kBlock) cnt[q] = 0;
+  __syncthreads();
+  const int wbase = w * kWbPerWave;
+  int next = kWave;  // next word of the wave (relative to wbase) that no lane has taken
+  int widx = wbase + lane;
+  bool active = a0 + static_cast<size_t>(widx) < na;
+  typename Step::State s{0, 0};
+  StagedOut o{stage + widx, a.emit, 0, 0, kWbWords};
+  if (active) {
+    const uint32_t start = anchors[a0 + widx];
+    s = typename Step::State{start, start};
+    o.spill = a.emit + start;
+  }
+  for (;;) {
+    if (active) {
+      const bool done = s.p >= a.n_text || Step::step(a, s, o);
+      if (done) {
+        cnt[widx] = o.c;
+        active = false;
+      }
+    }
+    const uint64_t idle = __ballot(!active);
+    if (next < kWbPerWave) {  // (wave-uniform)
+      if (!active) {
+        const int cand = next + __popcll(idle & ((1ull << lane) - 1ull));
+        if (cand < kWbPerWave && a0 + static_cast<size_t>(wbase + cand) < na) {
+          widx = wbase + cand;
+          const uint32_t start = anchors[a0 + widx];
+          s = typename Step::State{start, start};
+          o = StagedOut{stage + widx, a.emit + start, 0, 0, kWbWords};
+          active = true;
+        }
+      }
+      next += __popcll(idle);
+    }
+    if (!__ballot(active)) break;
+  }
+  __syncthreads();
+  // the lists of the words, one behind the other: thread t appends words kPer * t ...
+  constexpr int kPer = kWbWords / kBlock;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int q = 0; q < kPer; q++) mine += cnt[threadIdx.x * kPer + q];
+  uint32_t tot;
+  uint32_t ex = block_excl_sum(mine, sm, tot);
+  const size_t base = a0 < na ? anchors[a0] : 0;
+#pragma unroll
+  for (int q = 0; q < kPer; q++) {
+    const int wq = threadIdx.x * kPer + q;
+    const uint32_t c = cnt[wq];
+    if (c == 0) continue;
+    const int32_t *spill = c > static_cast<uint32_t>(kStageIds) ? a.emit + anchors[a0 + wq] : nullptr;
+    for (uint32_t j = 0; j < c; j++) {
+      ctmp[base + ex + j] = j < static_cast<uint32_t>(kStageIds) ? stage[j * kWbWords + wq] : spill[j];
+    }
+    ex += c;
+  }
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
+}
+
+// ids[blk_off[b] ...] = the list of workgroup b (of the walk kernel, which took `words` anchors per workgroup)
 __global__ __launch_bounds__(kBlock) void emit_gather_kernel(const uint32_t *__restrict__ anchors,
                                                              const uint32_t *__restrict__ n_anchors_dev, size_t cap,
                                                              const int32_t *__restrict__ ctmp,
                                                              const uint32_t *__restrict__ blk_cnt,
                                                              const uint32_t *__restrict__ blk_off,
-                                                             int32_t *__restrict__ ids) {
-  const size_t k0 = static_cast<size_t>(blockIdx.x) * kBlock;
+                                                             int32_t *__restrict__ ids, int words) {
+  const size_t k0 = static_cast<size_t>(blockIdx.x) * words;
   if (k0 >= cap || k0 >= *n_anchors_dev) return;
   const size_t base = anchors[k0], off = blk_off[blockIdx.x];
   const uint32_t cnt = blk_cnt[blockIdx.x];
