@@ -110,7 +110,29 @@ template <typename Out>
 __device__ __forceinline__ bool walk_step(const WalkArgs &a, WalkState &s, Out &o) {
   const size_t end = a.n_text;
   size_t p = s.p;
-  const bool prefix = w_word_prefix(a, p);
+  // The class bytes of positions p-1 .. p+14 in two registers, loaded next to the rank (a token is a chain of
+  // dependent loads: every class test behind the token's end would otherwise add a link to it)
+  const size_t wbase = p ? p - 1 : 0;
+  uint64_t w0 = 0, w1 = 0;
+  const bool win = wbase + 16 <= end;
+  if (win) {
+    __builtin_memcpy(&w0, a.cls + wbase, 8);
+    __builtin_memcpy(&w1, a.cls + wbase + 8, 8);
+  }
+  auto cb = [&](size_t q) -> uint8_t {
+    const size_t d = q - wbase;
+    if (win && d < 16) return static_cast<uint8_t>((d < 8 ? w0 >> (8 * d) : w1 >> (8 * (d - 8))) & 0xffu);
+    return a.cls[q];
+  };
+  auto word_prefix = [&](size_t q) { return q == 0 || (cb(q) & kClsSpacing) || (cb(q - 1) & kClsSpacing); };
+  auto space = [&](size_t q) { return (cb(q) & kClsSpace) != 0; };
+  auto anchor = [&](size_t q) {
+    if (a.aflags) return a.aflags[q] != 0;
+    const uint8_t c = cb(q);
+    if (c & kClsSpace) return false;
+    return q == 0 || w_hard(c) || w_hard(cb(q - 1));
+  };
+  const bool prefix = word_prefix(p);
   const uint32_t r = rank_of(a.rank[p]);
   const int k = step_lookup(a.steps, r);
   int32_t id = prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
@@ -118,7 +140,7 @@ __device__ __forceinline__ bool walk_step(const WalkArgs &a, WalkState &s, Out &
   if (id != -1) {
     o.push(p, id);
     p += static_cast<size_t>(a.tok_len[id]);
-    if (p < end && w_word_prefix(a, p)) {
+    if (p < end && word_prefix(p)) {
       s.since = p;
       o.word_start();
     }
@@ -127,7 +149,7 @@ __device__ __forceinline__ bool walk_step(const WalkArgs &a, WalkState &s, Out &
     o.rollback(s.since, p);
     o.push(p, a.unk_id);
     ++p;
-    while (p < end && !w_word_prefix(a, p)) {
+    while (p < end && !word_prefix(p)) {
       ++p;
       // coverage mode (texts with very long words): jump over whole tiles without a word-prefix
       // position instead of stepping through them (a 10 M-char word otherwise costs a lane 2 s)
@@ -140,12 +162,12 @@ __device__ __forceinline__ bool walk_step(const WalkArgs &a, WalkState &s, Out &
     o.word_start();
   }
   s.p = p;
-  if (p < end && w_space(a, p)) {
+  if (p < end && space(p)) {
     // class rule with only hard spacing chars: the first position behind the spaces is an anchor of
     // its own, whatever it is — no need to step through the run (a megabyte of blanks otherwise
     // stalls this lane for 0.2 s)
     if (!a.aflags && a.all_hard) return true;
-    while (p < end && w_space(a, p)) {
+    while (p < end && space(p)) {
       ++p;
       if (a.ns_from_tile && (p & (kReachTile - 1)) == 0 && p < end) {  // coverage mode: jump over blank tiles
         p = min(static_cast<size_t>(a.ns_from_tile[p / kReachTile]), end);
@@ -154,9 +176,9 @@ __device__ __forceinline__ bool walk_step(const WalkArgs &a, WalkState &s, Out &
     }
     s.p = p;
   }
-  if (p >= end || w_anchor(a, p)) return true;
+  if (p >= end || anchor(p)) return true;
   // after skipped spaces p is a word-prefix position: counter restarts
-  if (w_word_prefix(a, p)) {
+  if (word_prefix(p)) {
     s.since = p;
     o.word_start();
   }
