@@ -261,14 +261,17 @@ __device__ __forceinline__ int count_key_symbols(uint64_t key, int t, const uint
   return cnt;
 }
 
-// First index in [lo, hi] whose key is >= key (hi: a position known to qualify, or the end of the array), by a
-// 64-way search of the whole wave: every step the lanes probe 64 evenly spaced positions with ONE load
-// instruction and a ballot picks the stretch that holds the answer — 5 dependent loads for 1e8 sorted keys
-// instead of the 27 of a binary search (the searches of this path are latency chains, not bandwidth).
+// First index in [lo, hi] whose key is >= key (hi: a position known to qualify, or the end of the array).  The
+// searches of this path are latency chains, not bandwidth: while the range is wide the whole wave probes 64 evenly
+// spaced positions with ONE load instruction and a ballot picks the stretch that holds the answer (3 steps from
+// 1e8 keys down to a few hundred, and the probes of the first two steps are the same cache lines for every search:
+// L2 hits); the last few hundred keys are finished by a binary search (a 64-way step there would pull in 64 lines
+// of its own per search where the binary search touches 3).  12 dependent loads instead of 27.
 // All 64 lanes must be active; every lane returns the same index.
+constexpr size_t kWaveSearchNarrow = 512;
 __device__ __forceinline__ size_t wave_key_lower_bound(const Key0 *__restrict__ keys, size_t lo, size_t hi, uint64_t key) {
   const size_t lane = static_cast<size_t>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
-  while (lo < hi) {
+  while (hi - lo > kWaveSearchNarrow) {
     const size_t st = (hi - lo) / kWave + 1;
     const size_t idx = lo + lane * st;
     const bool ge = idx < hi ? static_cast<uint64_t>(keys[idx]) >= key : true;
@@ -282,6 +285,10 @@ __device__ __forceinline__ size_t wave_key_lower_bound(const Key0 *__restrict__ 
     if (t) lo += (t - 1) * st + 1;
     hi = first_ge < hi ? first_ge : hi;
     if (!t) hi = lo;
+  }
+  while (lo < hi) {  // (uniform: the loads broadcast)
+    const size_t md = (lo + hi) >> 1;
+    if (static_cast<uint64_t>(keys[md]) < key) lo = md + 1; else hi = md;
   }
   return lo;
 }

@@ -615,24 +615,21 @@ __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restr
       } else if (neq) {
         carry = wave_base - static_cast<size_t>(__ffsll(static_cast<long long>(neq)) - 1);
       } else {
-        // a group of more than 64 entries reaches in.  Its first entry: gallop backwards (64 probes per load,
-        // 64, 4096, 262144, ... entries apart) to the stretch where the keys change, then the 64-way search —
-        // two dependent loads for groups of up to 4096 entries, where a binary search from the front of the
-        // array took 27 and made this kernel a latency chain (most spans start inside a large group)
-        size_t hi = wave_base - kWave, lo = 0, step = kWave;  // keys[hi] == me0
-        for (;;) {
-          const size_t back = step * static_cast<size_t>(lane + 1);
-          const bool valid = hi >= back;
+        // a group of more than 64 entries reaches in.  Its first entry: ONE load with the lanes 64, 128, 256, ...
+        // entries further back (27 probes reach past 2^32) brackets it between two probes, then the wave search
+        // inside the bracket — where a binary search from the front of the array took 27 dependent loads and made
+        // this kernel a latency chain (most spans start inside a large group), and 64 evenly spaced probes per
+        // step pulled in 8 KB of foreign cache lines per 4 KB span
+        size_t hi = wave_base - kWave, lo = 0;  // keys[hi] == me0
+        {
+          const size_t back = static_cast<size_t>(kWave) << (lane < 40 ? lane : 40);
+          const bool valid = lane < 40 && hi >= back;
           const bool eq = valid && keys[hi - back] == me0;
-          const uint64_t nm = ~__ballot(eq);
-          if (nm) {  // the nearest probe with another key (or in front of the array)
-            const size_t t = static_cast<size_t>(__ffsll(static_cast<long long>(nm)) - 1);
-            lo = hi >= step * (t + 1) ? hi - step * (t + 1) + 1 : 0;
-            hi -= step * t;
-            break;
-          }
-          hi -= step * kWave;
-          step *= kWave;
+          const uint64_t nm = ~__ballot(eq);  // (never 0: the high lanes are not valid)
+          const int t = __ffsll(static_cast<long long>(nm)) - 1;  // the nearest probe with another key, or in front of the array
+          const size_t back_t = static_cast<size_t>(kWave) << t, back_in = t ? static_cast<size_t>(kWave) << (t - 1) : 0;
+          lo = hi >= back_t ? hi - back_t + 1 : 0;
+          hi -= back_in;
         }
         carry = wave_key_lower_bound(keys, lo, hi, static_cast<uint64_t>(me0));
       }
