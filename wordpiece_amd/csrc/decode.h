@@ -268,7 +268,10 @@ __device__ __forceinline__ int count_key_symbols(uint64_t key, int t, const uint
 // L2 hits); the last few hundred keys are finished by a binary search (a 64-way step there would pull in 64 lines
 // of its own per search where the binary search touches 3).  12 dependent loads instead of 27.
 // All 64 lanes must be active; every lane returns the same index.
-constexpr size_t kWaveSearchNarrow = 512;
+#ifndef WP_WAVE_SEARCH_NARROW
+#define WP_WAVE_SEARCH_NARROW 512
+#endif
+constexpr size_t kWaveSearchNarrow = WP_WAVE_SEARCH_NARROW;
 __device__ __forceinline__ size_t wave_key_lower_bound(const Key0 *__restrict__ keys, size_t lo, size_t hi, uint64_t key) {
   const size_t lane = static_cast<size_t>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
   while (hi - lo > kWaveSearchNarrow) {

@@ -736,7 +736,8 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     db.tail_mask = (1u << (win_mid - kWinBits)) - 1u;
     db.tail_from_val = true;
   }
-  // histogram by LDS atomics for the digits below this bit (near-uniform digits), by match-any ballots above
+  // histogram: one per-wave LDS counter per digit for the digits below this bit (near-uniform: the tail of a
+  // compressed codeword stream), 8 interleaved copies of the counters above it (skewed digits; radix_sort.h)
   static const int hist_atomic_bits = getenv("WP_HIST_ATOMIC_BITS") ? atoi(getenv("WP_HIST_ATOMIC_BITS")) : 8;
   // (round-0 keys of up to 32 bits live as uint32 in the first half of the 64-bit key buffers)
   // (round-0 keys of up to 32 bits live as uint32 in the first half of the 64-bit key buffers)
