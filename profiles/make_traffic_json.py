@@ -15,7 +15,7 @@ import sys
 
 base, tag = sys.argv[1], sys.argv[2]
 ITEMS = 16  # WP_RADIX_ITEMS32: 32-bit round-0 keys, 8-byte records (round 1: <unsigned long, 24>)
-KEY = "radix_scatter_kernel<unsigned int, %d>" % ITEMS
+KEY = "radix_scatter_kernel<unsigned int, %d" % ITEMS  # (any value source: PlainVals, RankVals)
 HIST = "radix_hist_kernel<unsigned int, %d>" % ITEMS
 
 
@@ -34,17 +34,16 @@ def per_kernel(counter):
 
 ft, fc, fg = per_kernel("FETCH_SIZE")
 wt, wc, _ = per_kernel("WRITE_SIZE")
-name = [k for k in ft if KEY in k][0]
-hist = [k for k in ft if HIST in k][0]
+names = [k for k in ft if KEY in k]  # (every value source of the full-size scatter: PlainVals, RankVals)
 # bench.py --steps 1 --warmup 1 encodes twice (+ once more for the oracle sample check): per-launch
 # averages do not depend on the number of steps
-launches = fc[name]
+launches = sum(fc[k] for k in names)
 # Check of the x2 factor on a kernel with a known read: the plain device-to-device copy of the bench set-up is
 # not in the trace, so the check uses the scatter kernel itself: records read = 8 B per element (4 B in the
 # first pass of the sort, whose index column is made up) + 1 digit byte is NOT read by it
 factor = None
-fetch = 2.0 * ft[name] / launches
-write = wt[name] / wc[name]
+fetch = 2.0 * sum(ft[k] for k in names) / launches
+write = sum(wt[k] for k in names) / sum(wc[k] for k in names)
 bench = json.load(open(os.path.join(base, "%s_bench.json" % tag)))
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 out = {

@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "decode_count" in r["Kernel_Name"]]
-ranks = [i for i, r in enumerate(rows) if "round0_rank" in r["Kernel_Name"]]
+ranks = [i for i, r in enumerate(rows) if "need_groups" in r["Kernel_Name"] or "round0_rank" in r["Kernel_Name"]]
 last = ranks[-1]
 s = max(i for i in starts if i < last)
 e = min([i for i in starts if i > last] + [len(rows)])

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <future>
 #include <memory>
 #include <mutex>
@@ -696,8 +697,13 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   // 2^4 for 1e8 positions: with uniform digits the runs a tile appends to its bins are 4096 / bins entries, and
   // 16-entry runs leave the workgroup as half lines: 0.51 ms for that pass against 0.34 ms)
   const int win_mid = hb_n - kWinBits <= kRadixBits ? hb_n : kWinBits + (hb_n - kWinBits + 1) / 2;
+  // rank_in_pass != nullptr: the first pass computes the ranks itself from the sorted keys (suffix_array.h,
+  // RankVals) — there is no rank array then (val == nullptr), and pair a must not be the key buffer.
+  // before_second: called between the two passes (the side stream's searches in the keys must be over before pair
+  // b, which may be the key buffer, is written).
   auto store_ranks_round0 = [&](uint32_t *dst, uint32_t *val, uint32_t *a_dst, uint32_t *a_val, uint32_t *b_dst,
-                                uint32_t *b_val, uint8_t *dig, uint8_t *other) {
+                                uint32_t *b_val, uint8_t *dig, uint8_t *other, const RankVals *rank_in_pass,
+                                const std::function<void()> &before_second) {
     // (a per-device attribute: set on every call, the context may live on any device)
     WP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(window_store_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kWinLdsBytes)));
@@ -710,8 +716,9 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       d1.tail_bit = mid;
       d1.tail_mask = (1u << (hb_n - mid)) - 1u;
     }
-    radix_sort_pairs<uint32_t>(dst, val, a_dst, a_val, n, kWinBits, mid, d_radix_tmp, radix_words, st, &c->rstats, false,
-                               hb_n + 1, d1);
+    radix_sort_pairs<uint32_t, RankVals>(dst, val, a_dst, a_val, n, kWinBits, mid, d_radix_tmp, radix_words, st,
+                                         &c->rstats, false, hb_n + 1, d1, rank_in_pass);
+    if (before_second) before_second();
     const uint32_t *f_dst = a_dst, *f_val = a_val;
     if (mid < hb_n) {
       DigitBytes d2;
@@ -770,6 +777,10 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       hipLaunchKernelGGL(widen_keys_kernel, dim3(std::min<size_t>(cdiv(n, kBlock), 8192)), dim3(kBlock), 0, st, keys, LK1, n);
       return LK1;
     };
+    // text-only layout, full-size rank store: no rank kernel — the first partition pass of the rank store computes
+    // the ranks and the depths of the tied groups from the sorted keys (suffix_array.h, RankVals)
+    static const bool env_no_fusion = env_flag("WP_NO_RANK_FUSION");
+    const bool fuse_rank = prune && window_store && !d_lcp && !v->keep_debug && !v->lcp_kasai && !env_no_fusion;
     if (prune) {
       // Depth-capped mode: the groups that have to go on are found from the vocabulary (prune.h) and appended
       // to the active list by the kernel that finds them — on the side stream (a few thousand waves of
@@ -791,7 +802,9 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
         hipLaunchKernelGGL(needed_need_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st2, nl);  // (a needed group per token at most)
         hipLaunchKernelGGL(needed_fill_kernel, dim3(1024), dim3(kBlock), 0, st2, nl, vals, n);
       }
-      if (d_lcp) {
+      if (fuse_rank) {
+        // (the ranks are computed inside the first partition pass of the rank store, below)
+      } else if (d_lcp) {
         hipLaunchKernelGGL(round0_rank_kernel<true>, dim3(cdiv(n, kR0Tile)), dim3(kBlock), 0, st, keys, vals, n,
                            dcode.first_len, dcode.uniform_bits, (v->keep_debug || v->lcp_kasai) ? d_sa : nullptr, hd, d_lcp,
                            d_gdepth);
@@ -800,7 +813,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
                            dcode.first_len, dcode.uniform_bits, (v->keep_debug || v->lcp_kasai) ? d_sa : nullptr, hd, d_lcp,
                            d_gdepth);
       }
-      join();  // the rank store below reuses the key buffer as scratch: the searches in it must be over
+      if (!fuse_rank) join();  // the rank store below reuses the key buffer as scratch: the searches in it must be over
     } else if (fused_rerank) {
       WP_HIP(hipMemsetAsync(lb.wa, 0, lb_bytes, st));
       hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_fused_kernel<SymT, true>), dim3(tiles), dim3(kBlock), 0, st, keys64(),
@@ -824,10 +837,17 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
                          slots, other_vals, AG, adep, d_ghead, d_gdepth, c->d_scalars + 4);
     }
     fork();
-    if (window_store) {
+    if (fuse_rank) {
+      // pair a = large-group buffers (idle in round 0), pair b = behind hd and the key buffer, which the side
+      // stream's searches and the first pass itself still read until the join
+      const RankVals rv{keys, dcode.first_len, dcode.uniform_bits, d_gdepth};
+      store_ranks_round0(vals, nullptr, LV0, LV1, reinterpret_cast<uint32_t *>(hd) + ((n + 3) & ~static_cast<size_t>(3)),
+                         reinterpret_cast<uint32_t *>(keys), DG0 ? db.tail_out(cur) : nullptr,
+                         DG0 ? db.tail_out(cur ^ 1) : nullptr, &rv, [&] { join(); });
+    } else if (window_store) {
       store_ranks_round0(vals, hd, reinterpret_cast<uint32_t *>(hd) + ((n + 3) & ~static_cast<size_t>(3)),
                          reinterpret_cast<uint32_t *>(keys), LV0, LV1, DG0 ? db.tail_out(cur) : nullptr,
-                         DG0 ? db.tail_out(cur ^ 1) : nullptr);
+                         DG0 ? db.tail_out(cur ^ 1) : nullptr, nullptr, nullptr);
     } else {
       store_ranks(vals, hd, reinterpret_cast<uint32_t *>(hd) + n, reinterpret_cast<uint32_t *>(keys), n);
     }

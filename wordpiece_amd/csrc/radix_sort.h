@@ -291,9 +291,25 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned ntiles) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
 }
 
-template <typename KeyT, int ITEMS>
+// Where the values of a pass come from.  PlainVals: the value column (nullptr: the identity, made up by the
+// first pass of a sort).  Another source (suffix_array.h, RankVals) computes them from data the pass would
+// otherwise have had written and read back; it may use the two LDS staging arrays (one kBlock * ITEMS words
+// each), which are idle until the ranking is done.
+struct PlainVals {
+  const uint32_t *vin;
+  template <int ITEMS>
+  __device__ __forceinline__ void fill(uint32_t (&val)[ITEMS], size_t wave_base, int lane, size_t n, uint32_t *, uint32_t *) const {
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+      const size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
+      val[r] = i < n ? (vin ? vin[i] : static_cast<uint32_t>(i)) : 0u;  // vin == nullptr: the identity
+    }
+  }
+};
+
+template <typename KeyT, int ITEMS, typename VS = PlainVals>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
-    const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
+    const KeyT *__restrict__ kin, VS vs, KeyT *__restrict__ kout,
     uint32_t *__restrict__ vout, size_t n, int begin_bit, uint32_t mask,
     const uint32_t *__restrict__ goff, uint8_t *__restrict__ dout, int next_bit, uint32_t next_mask, int dig_from_val) {
   // dout != nullptr: also leave the next pass's digit of every key as one byte at its new position,
@@ -330,8 +346,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
     const bool valid = i < n;
     key[r] = valid ? kin[i] : static_cast<KeyT>(~static_cast<KeyT>(0));
-    val[r] = valid ? (vin ? vin[i] : static_cast<uint32_t>(i)) : 0u;  // vin == nullptr: the identity
   }
+  vs.template fill<ITEMS>(val, wave_base, lane, n, reinterpret_cast<uint32_t *>(skeys), svals);
   volatile uint32_t *mycnt = wcnt[w];
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
@@ -476,10 +492,12 @@ struct DigitBytes {
   uint8_t *tail_out(int cur) const { return cur ? dg1 : dg0; }
 };
 
-template <typename KeyT>
+// first_vals != nullptr: the value source of the FIRST pass (full-size configuration only)
+template <typename KeyT, typename FV = PlainVals>
 int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, const BitRange *ranges,
                       int nranges, uint32_t *tmp, size_t tmp_words, hipStream_t st, RadixStats *stats,
-                      bool identity_vals = false, int uniform_low_bits = 0, DigitBytes db = DigitBytes()) {
+                      bool identity_vals = false, int uniform_low_bits = 0, DigitBytes db = DigitBytes(),
+                      const FV *first_vals = nullptr) {
   int cur = 0;
   if (n == 0) return cur;
   const bool small = n <= kRadixSmallN;
@@ -537,12 +555,16 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
       hipLaunchKernelGGL(radix_apply_kernel, dim3(nchunks), dim3(kRadixBins), 0, st, table, chunk_pre, ntiles);
     }
     if (stats) stats->spans.begin(st);
-    const uint32_t *vsrc = identity_vals ? static_cast<const uint32_t *>(nullptr) : vi;
+    const PlainVals vsrc{identity_vals ? static_cast<const uint32_t *>(nullptr) : vi};
     if (small) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kSmallItems>), dim3(ntiles),
+      if (first_vals) throw std::logic_error("radix_sort_ranges: a value source needs the full-size configuration");
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kSmallItems, PlainVals>), dim3(ntiles),
                          dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
+    } else if (first_vals && pi == 0) {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, FV>), dim3(ntiles),
+                         dim3(kBlock), 0, st, ki, *first_vals, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
     } else {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems>), dim3(ntiles),
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, PlainVals>), dim3(ntiles),
                          dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
     }
     identity_vals = false;
@@ -558,13 +580,13 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
   return cur;
 }
 
-template <typename KeyT>
+template <typename KeyT, typename FV = PlainVals>
 int radix_sort_pairs(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, int begin_bit, int end_bit,
                      uint32_t *tmp, size_t tmp_words, hipStream_t st, RadixStats *stats, bool identity_vals = false,
-                     int uniform_low_bits = 0, DigitBytes db = DigitBytes()) {
+                     int uniform_low_bits = 0, DigitBytes db = DigitBytes(), const FV *first_vals = nullptr) {
   BitRange r{begin_bit, end_bit};
-  return radix_sort_ranges<KeyT>(k0, v0, k1, v1, n, &r, 1, tmp, tmp_words, st, stats, identity_vals, uniform_low_bits,
-                                 db);
+  return radix_sort_ranges<KeyT, FV>(k0, v0, k1, v1, n, &r, 1, tmp, tmp_words, st, stats, identity_vals,
+                                     uniform_low_bits, db, first_vals);
 }
 
 }  // namespace wp

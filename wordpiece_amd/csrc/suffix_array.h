@@ -16,6 +16,7 @@
 #pragma once
 #include "decode.h"
 #include "primitives.h"
+#include "radix_sort.h"
 
 namespace wp {
 
@@ -729,6 +730,97 @@ __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restr
     }
   }
 }
+
+// ---- round 0 inside the rank store's first partition pass -------------------------------------------------
+// The first partition pass of the rank store reads (position, rank) in suffix order; the rank is the first slot of
+// the suffix's group, which the pass can see for itself in the sorted keys (4 bytes per entry, what reading the
+// rank would have cost).  As the value source of that radix scatter, round0_rank_kernel<false> disappears: no rank
+// array written and read back (0.8 GB per 1e8 suffixes), one full-size launch less.  Same logic as the kernel
+// above in the scatter's layout (a wave takes ITEMS rounds of 64 consecutive entries): group heads by ballots, the
+// head carried in from the entries in front of the wave by the same look-back, and the heads of tied groups
+// listed in the (still idle) LDS staging arrays and walked densely for the depth of their keys.
+struct RankVals {
+  const Key0 *sk;            // the sorted keys
+  const uint8_t *first_len;  // decode table of the symbol code (global: 8 KB, L1-resident)
+  int uniform_bits;
+  uint32_t *gdepth;
+  template <int ITEMS>
+  __device__ __forceinline__ void fill(uint32_t (&val)[ITEMS], size_t wave_base, int lane, size_t n, uint32_t *sa, uint32_t *sb) const {
+    const Key0 *__restrict__ keys = sk;
+    Key0 k[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+      const size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
+      k[r] = i < n ? keys[i] : static_cast<Key0>(0);
+    }
+    if (wave_base >= n) {  // (wave-uniform: only in the last tile)
+#pragma unroll
+      for (int r = 0; r < ITEMS; r++) val[r] = 0u;
+      return;
+    }
+    const bool have_front = wave_base >= 1 + static_cast<size_t>(lane);
+    const Key0 front = have_front ? keys[wave_base - 1 - lane] : static_cast<Key0>(0);
+    const size_t after_idx = wave_base + static_cast<size_t>(ITEMS) * kWave;
+    const Key0 after = after_idx < n ? keys[after_idx] : static_cast<Key0>(0);
+    size_t carry = wave_base;
+    {
+      const Key0 me0 = __shfl(k[0], 0, kWave);
+      const uint64_t neq = ~__ballot(have_front && front == me0);
+      if (neq & 1ull) {
+        carry = wave_base;
+      } else if (neq) {
+        carry = wave_base - static_cast<size_t>(__ffsll(static_cast<long long>(neq)) - 1);
+      } else {  // (see round0_rank_kernel)
+        size_t hi = wave_base - kWave, lo = 0;
+        const size_t back = static_cast<size_t>(kWave) << (lane < 40 ? lane : 40);
+        const bool valid = lane < 40 && hi >= back;
+        const bool eq = valid && keys[hi - back] == me0;
+        const uint64_t nm = ~__ballot(eq);
+        const int t = __ffsll(static_cast<long long>(nm)) - 1;
+        const size_t back_t = static_cast<size_t>(kWave) << t, back_in = t ? static_cast<size_t>(kWave) << (t - 1) : 0;
+        lo = hi >= back_t ? hi - back_t + 1 : 0;
+        hi -= back_in;
+        carry = wave_key_lower_bound(keys, lo, hi, static_cast<uint64_t>(me0));
+      }
+    }
+    const int w = wave_id();
+    volatile uint32_t *hpos = sa + static_cast<size_t>(w) * (ITEMS * kWave);
+    volatile Key0 *hkey = reinterpret_cast<Key0 *>(sb) + static_cast<size_t>(w) * (ITEMS * kWave);
+    static_assert(sizeof(Key0) <= sizeof(uint32_t), "the tied-head list lives in the 32-bit value staging array");
+    uint32_t listed = 0;  // (wave-uniform)
+    const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
+    Key0 prev_last = __shfl(front, 0, kWave);
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+      const size_t round_base = wave_base + static_cast<size_t>(r) * kWave;
+      const size_t i = round_base + lane;
+      const Key0 up = __shfl_up(k[r], 1, kWave), dn = __shfl_down(k[r], 1, kWave);
+      const Key0 next_first = r + 1 < ITEMS ? __shfl(k[r + 1 < ITEMS ? r + 1 : r], 0, kWave) : after;
+      const Key0 prevk = lane == 0 ? prev_last : up;
+      const Key0 nextk = lane == kWave - 1 ? next_first : dn;
+      const bool valid = i < n;
+      const bool f = valid && (i == 0 || prevk != k[r]);
+      const uint64_t bh = __ballot(f);
+      const uint64_t mine = bh & le;
+      const size_t head = mine ? round_base + static_cast<size_t>(63 - __clzll(static_cast<long long>(mine))) : carry;
+      val[r] = valid ? static_cast<uint32_t>(head) : 0u;
+      const bool tied = f && i + 1 < n && nextk == k[r];  // head of a tied group: its depth is wanted
+      const uint64_t bt = __ballot(tied);
+      if (tied) {
+        const uint32_t o = listed + static_cast<uint32_t>(__popcll(bt & lt));
+        hpos[o] = static_cast<uint32_t>(i);
+        hkey[o] = k[r];
+      }
+      listed += static_cast<uint32_t>(__popcll(bt));
+      if (bh) carry = round_base + static_cast<size_t>(63 - __clzll(static_cast<long long>(bh)));
+      prev_last = __shfl(k[r], kWave - 1, kWave);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t q = lane; q < listed; q += kWave) {
+      gdepth[hpos[q]] = static_cast<uint32_t>(count_key_symbols(static_cast<uint64_t>(hkey[q]), kKeyBits, first_len, uniform_bits));
+    }
+  }
+};
 
 // ---- single-pass form: the two passes fused with a chained scan ----------------------------------
 // The split of a round needs, per tile of the list, the exclusive prefix of three scalars (entries
