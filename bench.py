@@ -222,9 +222,11 @@ def main():
         steps = max(args.steps, 1)
         key_bytes = 4 if 0 < st["key_bits"] <= 32 else 8
         RADIX_BYTES_PER_ELEM = 2 * (key_bytes + 4)
-        scatter_name = "radix_scatter_kernel<%s> (full-size tiles: the %d passes of the round-0 suffix sort over %d-bit keys%s; %d-byte records)" % (
+        scatter_name = "radix_scatter_kernel<%s, PlainVals> (full-size tiles: the %d passes of the round-0 suffix sort over %d-bit keys%s; %d-byte records)" % (
             "uint32, 16" if key_bytes == 4 else "uint64, 24", (st["key_bits"] + 7) // 8, st["key_bits"],
-            " and the destination-partition passes of the round-0 rank store" if key_bytes == 4 else "", key_bytes + 4)
+            (" and the second destination-partition pass of the round-0 rank store (the first one also computes the ranks: "
+             "the RankVals instantiation, another kernel, not counted here)" if st["rank_in_pass"] else
+             " and the destination-partition passes of the round-0 rank store") if key_bytes == 4 else "", key_bytes + 4)
         ms_per_step = dt_max / args.steps * 1e3
         value = total_bytes / 1e6 / (dt_max / args.steps)
         # dominant kernel: the radix scatter pass.  Algorithmic bytes per launch = the (key, index) record read and
@@ -253,7 +255,7 @@ def main():
                        "sorted_depth": st["sorted_depth"], "symbol_bits": st["symbol_bits"],
                        "symbols_per_key": st["symbols_per_key"], "key_bits": st["key_bits"], "active_per_round": st["active_per_round"],
                        "needed_after_round0": st["needed_after_round0"],
-                       "radix_launches_per_step": radix_launches // steps, "staged_emit": st["staged_emit"],
+                       "radix_launches_per_step": radix_launches // steps, "staged_emit": st["staged_emit"], "rank_in_pass": st["rank_in_pass"],
                        "id_gather": ("%s: exact-size receives on rank 0" % ("rccl" if backend == "nccl" else backend)) if distributed
                        else "none (single GPU)"},
             "roofline": {"bound": "hbm", "kernel": scatter_name, "achieved": round(achieved, 1),
@@ -265,9 +267,10 @@ def main():
         # the whole SA/LCP stage against the HBM peak, SURVEY 8(d) style: algorithmic bytes only (no histogram
         # re-read of the keys: the histograms read the digit bytes)
         n_sym, act = st["n_total"], st["active_per_round"]
-        passes = radix_elems / steps
-        dig = (2 * digit_bytes / steps + n_sym) if digit_bytes else key_bytes * passes  # written + read (+ the key builder's bytes), or the key re-read
-        split = SPLIT_BYTES - (4 if st["vocab_in_s"] == 0 else 0)
+        passes = radix_elems / steps + (n_sym if st["rank_in_pass"] else 0)  # (+ the partition pass that computes the ranks)
+        dig = (2 * (digit_bytes / steps + (n_sym if st["rank_in_pass"] else 0)) + n_sym) if digit_bytes else key_bytes * passes  # written + read (+ the key builder's bytes), or the key re-read
+        # (rank_in_pass: no rank kernel at all — the first partition pass reads the sorted keys in place of the ranks)
+        split = 0 if st["rank_in_pass"] else SPLIT_BYTES - (4 if st["vocab_in_s"] == 0 else 0)
         sa_bytes = RADIX_BYTES_PER_ELEM * passes - 4 * n_sym + dig + (split + RANK_STORE_BYTES) * n_sym + ROUND_BYTES * sum(act[1:])
         sa_ms = stage_ms.get("ms_sa", 0.0) / steps
         if sa_ms > 0:

@@ -180,6 +180,9 @@ typedef struct {
   int32_t key_bits;           /* bits of the codeword stream in a round-0 key; keys of up to 32 bits
                                  are sorted as 8-byte (key, index) records, longer ones as 12-byte */
   int32_t staged_emit;        /* 1: ids left the walk as per-workgroup lists (see WP_OPT_SPARSE_EMIT) */
+  int32_t rank_in_pass;       /* 1: the ranks of round 0 were computed inside the first partition pass of the rank
+                                 store (one more full-size launch of the radix scatter, not in radix_passes) */
+  int32_t reserved1;
 } wp_stats;
 int wp_get_stats(const wp_vocab *v, wp_stats *out);
 

@@ -15,7 +15,7 @@ import sys
 
 base, tag = sys.argv[1], sys.argv[2]
 ITEMS = 16  # WP_RADIX_ITEMS32: 32-bit round-0 keys, 8-byte records (round 1: <unsigned long, 24>)
-KEY = "radix_scatter_kernel<unsigned int, %d" % ITEMS  # (any value source: PlainVals, RankVals)
+KEY = "radix_scatter_kernel<unsigned int, %d, wp::PlainVals>" % ITEMS  # (the plain scatter; RankVals also computes the ranks)
 HIST = "radix_hist_kernel<unsigned int, %d>" % ITEMS
 
 
@@ -47,7 +47,7 @@ write = sum(wt[k] for k in names) / sum(wc[k] for k in names)
 bench = json.load(open(os.path.join(base, "%s_bench.json" % tag)))
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 out = {
-    "kernel": "radix_scatter_kernel<uint32, %d>" % ITEMS,
+    "kernel": "radix_scatter_kernel<uint32, %d, PlainVals>" % ITEMS,
     "round": tag,
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 "
               "--warmup 1 --no-cpu-baseline` (profiles/collect.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md "

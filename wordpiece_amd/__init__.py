@@ -51,7 +51,8 @@ class Stats(C.Structure):
                 ("n_anchors", C.c_int64), ("anchor_mode", C.c_int32), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double),
                 ("radix_digit_bytes", C.c_int64), ("ms_host_total", C.c_double), ("guard_zones", C.c_int32),
                 ("n_devices", C.c_int32), ("vocab_in_s", C.c_int32), ("reserved0", C.c_int32),
-                ("needed_after_round0", C.c_int64), ("key_bits", C.c_int32), ("staged_emit", C.c_int32)]
+                ("needed_after_round0", C.c_int64), ("key_bits", C.c_int32), ("staged_emit", C.c_int32),
+                ("rank_in_pass", C.c_int32), ("reserved1", C.c_int32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "active_per_round"}

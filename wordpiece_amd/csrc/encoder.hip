@@ -716,8 +716,10 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       d1.tail_bit = mid;
       d1.tail_mask = (1u << (hb_n - mid)) - 1u;
     }
+    // (the roofline statistics describe the plain scatter: the instantiation that also computes the ranks is another kernel)
     radix_sort_pairs<uint32_t, RankVals>(dst, val, a_dst, a_val, n, kWinBits, mid, d_radix_tmp, radix_words, st,
-                                         &c->rstats, false, hb_n + 1, d1, rank_in_pass);
+                                         rank_in_pass ? nullptr : &c->rstats, false, hb_n + 1, d1, rank_in_pass);
+    S.rank_in_pass = rank_in_pass ? 1 : 0;
     if (before_second) before_second();
     const uint32_t *f_dst = a_dst, *f_val = a_val;
     if (mid < hb_n) {
