@@ -27,7 +27,7 @@ def make_case(rng, k):
     elif kind == 4:  # wide alphabet (> 255 symbols: u32 symbols, split code)
         alpha, tok_max, text_len = "".join(chr(c) for c in range(0x400, 0x400 + 300)) + " ab", 8, rng.randint(50, 5000)
     elif kind == 5:  # big case: full-size radix tiles and digit bytes (n > 2^21)
-        alpha, tok_max, text_len = "etaoinshr dlu ", 20, rng.randint(2_200_000, 3_000_000)
+        alpha, tok_max, text_len = "etaoinshr dlu ", 20, rng.randint(2_200_000, 5_200_000)  # (> 2^22: LDS-window rank store, ranks inside its first pass)
     elif kind == 6:  # invalid UTF-8 sprinkled in
         alpha, tok_max, text_len = "ab c", 10, rng.randint(10, 2000)
     else:
