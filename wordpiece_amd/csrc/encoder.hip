@@ -152,6 +152,14 @@ struct Context {
   uint32_t *d_used = nullptr, *d_lut = nullptr, *d_scan_tmp = nullptr;  // code point tables
   uint32_t *d_scalars = nullptr;                                         // kScalars words of device scalars
   uint8_t *d_code = nullptr;     // symbol code tables: cw u16[256] | len u8[256] | bmask u16[4096]
+  // The symbol code of the last encode, kept while the alphabet size stays the same: ANY order-preserving code over
+  // the dense symbol ids 0..sigma is correct (the histogram only steers the codeword lengths), so consecutive
+  // shards / batches of one corpus reuse it and skip the histogram download, the host-side construction and the
+  // table upload — one host round trip less per encode.  Rebuilt every kCodeReuse encodes to follow the text.
+  SymbolCode code_cache;
+  bool code_cached = false;
+  uint32_t code_alphabet = 0;
+  int code_bits = 0, code_lo = 0, code_uses = 0;
   uint8_t *h_code = nullptr;     // pinned staging of the same (the upload needs no host wait: every encode ends with one)
   uint32_t *d_symhist = nullptr;  // 256 counters
   uint32_t *h_scalars = nullptr;                                         // pinned mirror
@@ -611,15 +619,22 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   static const bool allow_variable = !(getenv("WP_FIXED_CODE") && atoi(getenv("WP_FIXED_CODE")) != 0);
   // alphabets > 255: the code covers symbol >> lo_bits (<= 256 values), the low bits follow verbatim
   const int lo_bits = sizeof(SymT) == 1 ? 0 : std::max(0, bits - 8);
-  WP_HIP(hipMemsetAsync(c->d_symhist, 0, sizeof(uint32_t) * 256, st));
+  constexpr int kCodeReuse = 64;
+  static const bool env_no_code_cache = env_flag("WP_NO_CODE_CACHE");
+  const bool reuse_code = allow_variable && !env_no_code_cache && c->code_cached && c->code_alphabet == static_cast<uint32_t>(S.alphabet) &&
+                          c->code_bits == bits && c->code_lo == lo_bits && c->code_uses < kCodeReuse;
+  if (!reuse_code) WP_HIP(hipMemsetAsync(c->d_symhist, 0, sizeof(uint32_t) * 256, st));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(decode_write_kernel<SymT>), dim3(cdiv(nbytes, kDecTile)), dim3(kBlock), 0, st,
                      d_text, nbytes, d_tile_prefix, c->d_lut, d_sym, d_cls, d_cps, c->d_soft,
-                     static_cast<int>(hv.soft.size()), allow_variable ? c->d_symhist : nullptr, lo_bits);
+                     static_cast<int>(hv.soft.size()), allow_variable && !reuse_code ? c->d_symhist : nullptr, lo_bits);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(map_vocab_symbols_kernel<SymT>), dim3(cdiv(n - n_text, kBlock)), dim3(kBlock), 0,
                      st, c->d_stream, n_text, n, c->d_lut, d_sym);
   if (n_text > 0 && anchor_at == 0) launch_anchors(true);
   SymbolCode code;
-  if (allow_variable) {
+  if (reuse_code) {
+    code = c->code_cache;  // (the device tables still hold it)
+    c->code_uses++;
+  } else if (allow_variable) {
     // frequencies of symbol >> lo_bits -> optimal order-preserving code (host, <= 256 items) -> device tables
     std::vector<uint32_t> h32(256);
     WP_HIP(hipMemcpyAsync(h32.data(), c->d_symhist, sizeof(uint32_t) * 256, hipMemcpyDeviceToHost, st));
@@ -637,7 +652,17 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   }
   DevCode dcode{reinterpret_cast<const uint16_t *>(c->d_code), c->d_code + 512, c->d_code + 768,
                 code.uniform_bits ? code.uniform_bits : -code.lo_bits};
-  if (!code.uniform_bits) {
+  if (allow_variable && !reuse_code) {
+    c->code_cache = code;
+    c->code_cached = true;
+    c->code_alphabet = static_cast<uint32_t>(S.alphabet);
+    c->code_bits = bits;
+    c->code_lo = lo_bits;
+    c->code_uses = 0;
+  } else if (!allow_variable) {
+    c->code_cached = false;
+  }
+  if (!code.uniform_bits && !reuse_code) {
     const size_t blob_bytes = 512 + 256 + kDecodeTableBytes;
     std::memset(c->h_code, 0, blob_bytes);
     std::memcpy(c->h_code, code.cw.data(), code.cw.size() * sizeof(uint16_t));
