@@ -280,3 +280,36 @@ print("DEBUG_BOUNDS_OK")
     env = dict(os.environ, WP_LIB=dbg)
     r = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "DEBUG_BOUNDS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_tuning_switches_do_not_change_ids(tmp_path):
+    """The environment switches select other forms of the same stages (README: "Results never depend on them"):
+    rank kernel as a launch of its own, round-1 rank store, one depth cap for all groups, symbol code rebuilt per
+    encode, match-any histograms, per-position id array, every tied group refined, the reference's S layout.
+    Each combination in a child process (the switches are read once per process) on inputs that reach the
+    full-size paths (> 2^22 symbols), against the oracle."""
+    script = tmp_path / "switch_run.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+import numpy as np
+import oracle_lib as O, wordpiece_amd as W
+from wordpiece_amd import synth
+cases = [synth.english_corpus(5_000_000, seed=71, vocab_size=6000),
+         synth.deep_prefix_corpus(4_500_000, seed=73),
+         (b"ab " * 7 + b"abab" * 300 + b" ab", ["a", "##b", "ab", "##ab", "abab", "[UNK]"])]
+for text, vocab in cases:
+    exp = O.Vocab(vocab).encode(text, threads=8)
+    gv = W.Vocab(vocab)
+    for _ in range(2):  # (second call: reused context, cached symbol code)
+        assert np.array_equal(gv.encode(text), exp)
+print("SWITCH_OK")
+''' % (os.path.dirname(PKG), os.path.dirname(os.path.abspath(__file__))))
+    combos = [{"WP_NO_RANK_FUSION": "1"}, {"WP_RANK_STORE_SCATTER": "1", "WP_HIST_SKEW": "0"},
+              {"WP_GLOBAL_NEED": "1", "WP_NO_CODE_CACHE": "1", "WP_SPARSE_EMIT": "1"},
+              {"WP_NO_PRUNE": "1"}, {"WP_VOCAB_IN_S": "1", "WP_NO_DIGIT_BYTES": "1"}]
+    for combo in combos:
+        env = dict(os.environ, **combo)
+        r = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "SWITCH_OK" in r.stdout, str(combo) + r.stdout[-1500:] + r.stderr[-1500:]

@@ -1172,18 +1172,12 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     // (a grid sized for the worst case, every position an anchor, costs 0.35 ms of empty workgroups)
     const size_t acap = std::max<size_t>(n_anchors, 1);
     const unsigned wblocks = cdiv(acap, kBlock);
-    static const bool env_lane_walk = env_flag("WP_LANE_PER_WORD");  // (A/B: one lane per word, no balancing)
     if (staged) {
       int32_t *d_ctmp = reinterpret_cast<int32_t *>(K0);  // (the key buffers are free after the suffix sort)
-      const int words = env_lane_walk ? kBlock : kWbWords;
+      const int words = kWbWords;
       const unsigned sblocks = cdiv(acap, static_cast<size_t>(words));
-      if (env_lane_walk) {
-        hipLaunchKernelGGL(walk_staged_kernel, dim3(sblocks), dim3(kBlock), 0, st, wa, d_anchors, c->d_scalars + 10, acap,
-                           d_ctmp, d_blk_cnt);
-      } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_balanced_kernel<WalkArgs, LinearStep>), dim3(sblocks), dim3(kBlock), 0, st, wa,
-                           d_anchors, c->d_scalars + 10, acap, d_ctmp, d_blk_cnt);
-      }
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_balanced_kernel<WalkArgs, LinearStep>), dim3(sblocks), dim3(kBlock), 0, st, wa,
+                         d_anchors, c->d_scalars + 10, acap, d_ctmp, d_blk_cnt);
       device_exclusive_scan(d_blk_cnt, d_blk_off, sblocks, d_emit_tmp, c->d_scalars + 9, st);
       hipLaunchKernelGGL(emit_gather_kernel, dim3(sblocks), dim3(kBlock), 0, st, d_anchors, c->d_scalars + 10, acap, d_ctmp,
                          d_blk_cnt, d_blk_off, d_ids, words);
@@ -1401,17 +1395,11 @@ static void encode_fast_on_device(const wp_vocab *v, Context *c, const uint8_t *
   }
   const size_t acap = std::max<size_t>(n_anchors, 1);
   const unsigned wblocks = cdiv(acap, kBlock);
-  static const bool env_lane_walk = env_flag("WP_LANE_PER_WORD");
   if (staged) {
-    const int words = env_lane_walk ? kBlock : kWbWords;
+    const int words = kWbWords;
     const unsigned sblocks = cdiv(acap, static_cast<size_t>(words));
-    if (env_lane_walk) {
-      hipLaunchKernelGGL(fast_walk_staged_kernel, dim3(sblocks), dim3(kBlock), 0, st, fa, d_anchors, c->d_scalars + 10, acap,
-                         d_lid, d_blk_cnt);  // (d_lid: the long-word id buffer, idle here)
-    } else {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_balanced_kernel<FastArgs, FastStep>), dim3(sblocks), dim3(kBlock), 0, st, fa,
-                         d_anchors, c->d_scalars + 10, acap, d_lid, d_blk_cnt);
-    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_balanced_kernel<FastArgs, FastStep>), dim3(sblocks), dim3(kBlock), 0, st, fa,
+                       d_anchors, c->d_scalars + 10, acap, d_lid, d_blk_cnt);  // (d_lid: the long-word id buffer, idle here)
     device_exclusive_scan(d_blk_cnt, d_blk_off, sblocks, d_emit_tmp, c->d_scalars + 9, st);
     hipLaunchKernelGGL(emit_gather_kernel, dim3(sblocks), dim3(kBlock), 0, st, d_anchors, c->d_scalars + 10, acap, d_lid,
                        d_blk_cnt, d_blk_off, d_ids, words);

@@ -282,24 +282,4 @@ __global__ __launch_bounds__(kBlock) void fast_walk_kernel(FastArgs a, const uin
   fast_walk_from(a, start, o);
 }
 
-// no long word in the text: the ids leave as per-workgroup lists (walk.h, StagedOut)
-__global__ __launch_bounds__(kBlock) void fast_walk_staged_kernel(FastArgs a, const uint32_t *__restrict__ anchors,
-                                                                  const uint32_t *__restrict__ n_anchors_dev, size_t cap,
-                                                                  int32_t *__restrict__ ctmp,
-                                                                  uint32_t *__restrict__ blk_cnt) {
-  __shared__ int32_t stage[kStageIds * kBlock];
-  __shared__ uint32_t sm[8];
-  const size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  const size_t na = min(cap, static_cast<size_t>(*n_anchors_dev));
-  const size_t k0 = static_cast<size_t>(blockIdx.x) * kBlock;
-  const size_t base = k0 < na ? anchors[k0] : 0;
-  StagedOut o{stage + threadIdx.x, a.emit, 0, 0, kBlock};
-  if (k < na) {
-    const uint32_t start = anchors[k];
-    o.spill = a.emit + start;
-    fast_walk_from(a, start, o);
-  }
-  flush_staged(o, base, ctmp, blk_cnt, sm);
-}
-
 }  // namespace wp

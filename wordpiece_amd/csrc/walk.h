@@ -49,8 +49,8 @@ __device__ __forceinline__ bool w_anchor(const WalkArgs &a, size_t p) {
 // ---- where a lane's ids go ---------------------------------------------------------------------------
 // SparseOut: emit[p] = id at the token's first position; emit_count / emit_write compact the array afterwards
 // (needed when several kernels contribute ids: long words, coverage anchors).
-// StagedOut: the lane keeps its ids — the first kStageIds in LDS, the rest at emit[p0 + j], inside the stretch
-// of text only this lane walks — and the workgroup appends them, lane after lane, to a compact list that
+// StagedOut: the ids of a word stay with it — the first kStageIds in LDS, the rest at emit[p0 + j], inside the
+// stretch of text only this word's lane walks — and the workgroup appends them, word after word, to a compact list that
 // starts at the position of its first anchor (a token consumes at least one position, so the list fits in
 // front of the next workgroup's first anchor).  emit_gather_kernel then moves whole lists: the id stream is
 // written and read once, 4 bytes per id, instead of a cleared 4-byte slot per text position.
@@ -90,15 +90,6 @@ struct StagedOut {
     return j < static_cast<uint32_t>(kStageIds) ? stage[j * stride] : spill[j];
   }
 };
-
-// the workgroup's lists, one behind the other, at ctmp[base...]; blk_cnt[block] = their total length
-__device__ __forceinline__ void flush_staged(const StagedOut &o, size_t base, int32_t *__restrict__ ctmp,
-                                             uint32_t *__restrict__ blk_cnt, uint32_t *sm) {
-  uint32_t tot;
-  const uint32_t ex = block_excl_sum(o.c, sm, tot);
-  for (uint32_t j = 0; j < o.c; j++) ctmp[base + ex + j] = o.get(j);
-  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
-}
 
 // One step of a lane's walk: the token at s.p (or the [UNK] of its word) and what follows it up to the next
 // token start.  Returns true when the lane's stretch of text ends (end of text, or the next anchor).
@@ -559,32 +550,12 @@ __global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a, const uint32_t
   walk_from(a, start, o);
 }
 
-// Class-rule anchors with only hard spacing chars and no long word (the common case): every lane walks exactly
-// one word, and the ids leave the kernel as per-workgroup lists (StagedOut).
-__global__ __launch_bounds__(kBlock) void walk_staged_kernel(WalkArgs a, const uint32_t *__restrict__ anchors,
-                                                             const uint32_t *__restrict__ n_anchors_dev, size_t cap,
-                                                             int32_t *__restrict__ ctmp, uint32_t *__restrict__ blk_cnt) {
-  __shared__ int32_t stage[kStageIds * kBlock];
-  __shared__ uint32_t sm[8];
-  const size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  const size_t na = min(cap, static_cast<size_t>(*n_anchors_dev));
-  const size_t k0 = static_cast<size_t>(blockIdx.x) * kBlock;
-  const size_t base = k0 < na ? anchors[k0] : 0;
-  StagedOut o{stage + threadIdx.x, a.emit, 0, 0, kBlock};
-  if (k < na) {
-    const uint32_t start = anchors[k];
-    o.spill = a.emit + start;
-    walk_from(a, start, o);
-  }
-  flush_staged(o, base, ctmp, blk_cnt, sm);
-}
-
 // A lane per word makes every wave wait for its longest word: 1.2 tokens per word on average, 7 in the slowest of
 // 64 lanes, and a token is a chain of ~5 dependent loads (the kernel ran 84 % waiting, 20 us per wave).  Here a
 // wave owns kWbPerWave consecutive words and deals them out as lanes fall idle: every iteration each busy lane
 // takes ONE token step (Step::step), then the idle lanes pick the next words in order (ballot + prefix count,
 // no atomics).  Ids are staged per word (first kStageIds in LDS, the rest in the word's own stretch of emit[])
-// and leave as one list per workgroup, in word order, like walk_staged_kernel's.
+// and leave as one list per workgroup, in word order.
 constexpr int kWbPerWave = 256;
 constexpr int kWbWords = kWbPerWave * (kBlock / kWave);
 struct LinearStep {
