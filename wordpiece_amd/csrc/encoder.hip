@@ -1020,6 +1020,8 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   if (n_text > 0 && anchor_at == 2) fork();
   StepTable steps{};
   MarkView mv{};
+  // (step values carry the token length above the id where both fit: scanline.h)
+  const int pack_steps = (hv.longest < kStepMaxLen && hv.tokens.size() < (size_t(1) << kStepIdBits) && !env_flag("WP_NO_STEP_PACK")) ? 1 : 0;
   {
     const size_t vocab_base = n_text + 1;
     uint32_t *mslot = d_mslot0, *midx = d_midx0;
@@ -1069,11 +1071,11 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
                                               st, nullptr);
     uint32_t *pstart = pc ? d_ps1 : d_ps0;
     hipLaunchKernelGGL(piece_values_kernel, dim3(cdiv(static_cast<size_t>(P) * kWave, kBlock)), dim3(kBlock), 0, st,
-                       mv, pstart, P, d_pval_p, d_pval_s);
+                       mv, pstart, P, d_pval_p, d_pval_s, pack_steps);
     hipLaunchKernelGGL(piece_bucket_kernel, dim3(cdiv(nbuckets + 1, kBlock)), dim3(kBlock), 0, st, pstart, P,
                        bucket_shift, nbuckets, d_bidx);
     WP_LAUNCH_CHECK();
-    steps = StepTable{pstart, d_pval_p, d_pval_s, d_bidx, bucket_shift};
+    steps = StepTable{pstart, d_pval_p, d_pval_s, d_bidx, bucket_shift, pack_steps};
   }
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[5], st));
 

@@ -25,6 +25,9 @@ constexpr int kSlItems = 16;
 constexpr int kSlTile = kBlock * kSlItems;  // 4096 SA slots per workgroup
 constexpr int32_t kLcpInf = 0x7fffffff;
 constexpr uint32_t kMarkLenMask = 0x0fffffffu;
+// step values with the token length packed above the id: ids < 2^20 lines, lengths < 2^11 symbols (the sign bit stays clear)
+constexpr int kStepIdBits = 20;
+constexpr int kStepMaxLen = 1 << 11;
 constexpr uint32_t kMarkSurvBwd = 1u << 28;  // on the stack when the right->left scan leaves the tile
 constexpr uint32_t kMarkSurvFwd = 1u << 29;  // on the stack when the left->right scan leaves the tile
 constexpr int kMarkClsShift = 30;            // 0 = prefix-class token, 1 = ##suffix-class token
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void piece_starts_kernel(MarkView mv, size_
 // symmetrically for the right->left scan).
 __global__ __launch_bounds__(kBlock) void piece_values_kernel(MarkView mv, const uint32_t *__restrict__ pstart,
                                                               int P, int32_t *__restrict__ pval_prefix,
-                                                              int32_t *__restrict__ pval_suffix) {
+                                                              int32_t *__restrict__ pval_suffix, int packed) {
   const int k = static_cast<int>((static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6);
   const int lane = lane_id();
   if (k >= P) return;
@@ -389,15 +392,19 @@ __global__ __launch_bounds__(kBlock) void piece_values_kernel(MarkView mv, const
   if (lane < 2) {
     const int c = lane;
     const int x = c ? xq[1] : xq[0], y = c ? yq[1] : yq[0];
-    int32_t r = -1;
+    int wq = -1;  // the winning mark
     if (x >= 0 && y >= 0) {  // linear.cpp:243-250: both -> x iff strictly longer, else y
       const int32_t xl = static_cast<int32_t>(mv.minfo[x] & kMarkLenMask), yl = static_cast<int32_t>(mv.minfo[y] & kMarkLenMask);
-      r = xl > yl ? mv.mid[x] : mv.mid[y];
+      wq = xl > yl ? x : y;
     } else if (x >= 0) {
-      r = mv.mid[x];
+      wq = x;
     } else if (y >= 0) {
-      r = mv.mid[y];
+      wq = y;
     }
+    int32_t r = wq >= 0 ? mv.mid[wq] : -1;
+    // packed: the token's length rides in the bits above its id (step_id / step_len below): the walk gets both
+    // with one load instead of id -> tok_len[id], one link less in its chain of dependent loads
+    if (packed && r >= 0) r |= static_cast<int32_t>(mv.minfo[wq] & kMarkLenMask) << kStepIdBits;
     (c ? pval_suffix : pval_prefix)[k] = r;
   }
 }
@@ -421,7 +428,15 @@ struct StepTable {
   const int32_t *pval_prefix, *pval_suffix;
   const uint32_t *bidx;
   int shift;
+  int packed;  // values are (token length << kStepIdBits) | id (-1 stays -1): vocabularies below the two limits
 };
+__device__ __forceinline__ int32_t step_id(const StepTable &st, int32_t raw) {
+  return (st.packed && raw >= 0) ? (raw & ((1 << kStepIdBits) - 1)) : raw;
+}
+// (raw >= 0)
+__device__ __forceinline__ int32_t step_len(const StepTable &st, int32_t raw, const int32_t *__restrict__ tok_len) {
+  return st.packed ? (raw >> kStepIdBits) : tok_len[raw];
+}
 
 // index of the step containing SA slot r (pstart[0] == 0, so it always exists)
 __device__ __forceinline__ int step_lookup(const StepTable &st, uint32_t r) {
@@ -440,8 +455,8 @@ __global__ __launch_bounds__(kBlock) void step_expand_kernel(StepTable st, size_
   const size_t x = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (x >= n) return;
   const int k = step_lookup(st, static_cast<uint32_t>(x));
-  best_prefix[x] = st.pval_prefix[k];
-  best_suffix[x] = st.pval_suffix[k];
+  best_prefix[x] = step_id(st, st.pval_prefix[k]);
+  best_suffix[x] = step_id(st, st.pval_suffix[k]);
 }
 
 }  // namespace wp

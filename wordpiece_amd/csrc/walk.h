@@ -126,11 +126,12 @@ __device__ __forceinline__ bool walk_step(const WalkArgs &a, WalkState &s, Out &
   const bool prefix = word_prefix(p);
   const uint32_t r = rank_of(a.rank[p]);
   const int k = step_lookup(a.steps, r);
-  int32_t id = prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
+  const int32_t raw = prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
+  int32_t id = step_id(a.steps, raw);
   if (!wp_in_bounds(id >= -1 && id < a.n_tokens, kSiteTokenId)) id = -1;
   if (id != -1) {
     o.push(p, id);
-    p += static_cast<size_t>(a.tok_len[id]);
+    p += static_cast<size_t>(step_len(a.steps, raw, a.tok_len));
     if (p < end && word_prefix(p)) {
       s.since = p;
       o.word_start();
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void reach_kernel(WalkArgs a, uint32_t *__r
       uint32_t r = static_cast<uint32_t>(q);
       if (!w_space(a, q)) {
         const int k = step_lookup(a.steps, rank_of(a.rank[q]));
-        const int32_t id = w_word_prefix(a, q) ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
+        const int32_t id = step_id(a.steps, w_word_prefix(a, q) ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k]);
         if (id != -1) r += static_cast<uint32_t>(a.tok_len[id]);
       }
       reach[q] = r;
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(kBlock) void long_word_next_kernel(WalkArgs a, cons
   uint32_t nx = j;
   if (!w_space(a, p)) {
     const int k = step_lookup(a.steps, rank_of(a.rank[p]));
-    id = w_word_prefix(a, p) ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
+    id = step_id(a.steps, w_word_prefix(a, p) ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k]);
     if (id != -1) {
       const size_t q = p + static_cast<size_t>(a.tok_len[id]);
       if (q < lw.end) nx = j + static_cast<uint32_t>(a.tok_len[id]);  // (q == end: the last token of the range)
