@@ -285,7 +285,7 @@ print("DEBUG_BOUNDS_OK")
 def test_tuning_switches_do_not_change_ids(tmp_path):
     """The environment switches select other forms of the same stages (README: "Results never depend on them"):
     rank kernel as a launch of its own, round-1 rank store, one depth cap for all groups, symbol code rebuilt per
-    encode, match-any histograms, per-position id array, every tied group refined, the reference's S layout.
+    encode, match-any histograms, per-position id array, plain step values, every tied group refined, the reference's S layout.
     Each combination in a child process (the switches are read once per process) on inputs that reach the
     full-size paths (> 2^22 symbols), against the oracle."""
     script = tmp_path / "switch_run.py"
@@ -306,7 +306,7 @@ for text, vocab in cases:
         assert np.array_equal(gv.encode(text), exp)
 print("SWITCH_OK")
 ''' % (os.path.dirname(PKG), os.path.dirname(os.path.abspath(__file__))))
-    combos = [{"WP_NO_RANK_FUSION": "1"}, {"WP_RANK_STORE_SCATTER": "1", "WP_HIST_SKEW": "0"},
+    combos = [{"WP_NO_RANK_FUSION": "1", "WP_NO_STEP_PACK": "1"}, {"WP_RANK_STORE_SCATTER": "1", "WP_HIST_SKEW": "0"},
               {"WP_GLOBAL_NEED": "1", "WP_NO_CODE_CACHE": "1", "WP_SPARSE_EMIT": "1"},
               {"WP_NO_PRUNE": "1"}, {"WP_VOCAB_IN_S": "1", "WP_NO_DIGIT_BYTES": "1"}]
     for combo in combos:
