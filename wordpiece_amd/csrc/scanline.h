@@ -339,7 +339,22 @@ __global__ __launch_bounds__(kBlock) void piece_values_kernel(MarkView mv, const
   const int lane = lane_id();
   if (k >= P) return;
   const uint32_t slot = pstart[k];
-  int lo = 0, hi = mv.M;  // first mark with slot > `slot`
+  int lo = 0, hi = mv.M;  // first mark with slot > `slot`: 64 probes per step while the range is wide (decode.h)
+  while (hi - lo > 64) {
+    const int st = (hi - lo) / kWave + 1;
+    const int idx = lo + lane * st;
+    const bool gt = idx < hi ? mv.mslot[idx] > slot : true;
+    const uint64_t m = __ballot(gt);
+    if (!m) {
+      lo += (kWave - 1) * st + 1;
+      continue;
+    }
+    const int t = __ffsll(static_cast<long long>(m)) - 1;
+    const int first_gt = lo + t * st;
+    if (t) lo += (t - 1) * st + 1;
+    hi = first_gt < hi ? first_gt : hi;
+    if (!t) hi = lo;
+  }
   while (lo < hi) {
     const int md = (lo + hi) >> 1;
     if (mv.mslot[md] <= slot) lo = md + 1; else hi = md;
