@@ -1093,7 +1093,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       max_anchor_gap = c->h_scalars[11];
     }
     const bool all_hard = hv.soft.empty();
-    const bool staged = staged_possible && max_anchor_gap <= kMaxAnchorGap;
+    bool staged = staged_possible && max_anchor_gap <= kMaxAnchorGap;
     if (staged_possible && !staged) WP_HIP(hipMemsetAsync(d_emit, 0x80, n_text * sizeof(int32_t), st));  // long words after all
     if (!v->cover_anchors && all_hard && max_anchor_gap > kMaxAnchorGap) {
       // words longer than a lane should walk (walk.h, "long words"): pointer doubling instead
@@ -1168,6 +1168,9 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       wa.wp_from_tile = d_wp_tiles;
       wa.ns_from_tile = d_ns_tiles;
       S.anchor_mode = 1;
+      // coverage anchors: every id still comes from the lanes of the walk kernel, each inside its own stretch
+      // [anchor, next anchor) — the id lists work as they do for the class rule (the cleared emit array is not used)
+      staged = !env_sparse_emit && !v->sparse_emit;
     }
     S.n_anchors = static_cast<int64_t>(n_anchors);
     // the anchor list and the cleared emit array were produced on the side stream; one lane per anchor
