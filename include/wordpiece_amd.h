@@ -144,7 +144,7 @@ int64_t wp_vocab_token_utf8(const wp_vocab *v, int64_t i, char *buf, size_t cap)
                                  Same token ids either way. */
 #define WP_OPT_SPARSE_EMIT 11 /* 1: the walk writes each id into a per-position array that is compacted
                                  afterwards, always.  Default 0: that path is taken only when several
-                                 kernels contribute ids (words longer than a lane walks, coverage anchors);
+                                 kernels contribute ids (words longer than a lane walks);
                                  otherwise every workgroup of the walk leaves one compact id list.
                                  Same token ids either way (also env WP_SPARSE_EMIT=1). */
 int wp_set_option(wp_vocab *v, int option, int64_t value);
