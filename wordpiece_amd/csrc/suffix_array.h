@@ -790,29 +790,32 @@ struct RankVals {
     uint32_t listed = 0;  // (wave-uniform)
     const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
     Key0 prev_last = __shfl(front, 0, kWave);
+    // (slots fit 32 bits: n <= 2e9)
+    const uint32_t wb32 = static_cast<uint32_t>(wave_base), n32 = static_cast<uint32_t>(n);
+    uint32_t carry32 = static_cast<uint32_t>(carry);
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
-      const size_t round_base = wave_base + static_cast<size_t>(r) * kWave;
-      const size_t i = round_base + lane;
+      const uint32_t round_base = wb32 + static_cast<uint32_t>(r) * kWave;
+      const uint32_t i = round_base + static_cast<uint32_t>(lane);
       const Key0 up = __shfl_up(k[r], 1, kWave), dn = __shfl_down(k[r], 1, kWave);
       const Key0 next_first = r + 1 < ITEMS ? __shfl(k[r + 1 < ITEMS ? r + 1 : r], 0, kWave) : after;
       const Key0 prevk = lane == 0 ? prev_last : up;
       const Key0 nextk = lane == kWave - 1 ? next_first : dn;
-      const bool valid = i < n;
+      const bool valid = i < n32;
       const bool f = valid && (i == 0 || prevk != k[r]);
       const uint64_t bh = __ballot(f);
       const uint64_t mine = bh & le;
-      const size_t head = mine ? round_base + static_cast<size_t>(63 - __clzll(static_cast<long long>(mine))) : carry;
-      val[r] = valid ? static_cast<uint32_t>(head) : 0u;
-      const bool tied = f && i + 1 < n && nextk == k[r];  // head of a tied group: its depth is wanted
+      const uint32_t head = mine ? round_base + static_cast<uint32_t>(63 - __clzll(static_cast<long long>(mine))) : carry32;
+      val[r] = valid ? head : 0u;
+      const bool tied = f && i + 1 < n32 && nextk == k[r];  // head of a tied group: its depth is wanted
       const uint64_t bt = __ballot(tied);
       if (tied) {
-        const uint32_t o = listed + static_cast<uint32_t>(__popcll(bt & lt));
-        hpos[o] = static_cast<uint32_t>(i);
+        const uint32_t o = listed + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(bt >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bt), 0u));
+        hpos[o] = i;
         hkey[o] = k[r];
       }
       listed += static_cast<uint32_t>(__popcll(bt));
-      if (bh) carry = round_base + static_cast<size_t>(63 - __clzll(static_cast<long long>(bh)));
+      if (bh) carry32 = round_base + static_cast<uint32_t>(63 - __clzll(static_cast<long long>(bh)));
       prev_last = __shfl(k[r], kWave - 1, kWave);
     }
     __builtin_amdgcn_wave_barrier();
