@@ -88,3 +88,31 @@ def test_file_entry_points_report_missing_files(tmp_path):
     empty = tmp_path / "empty.txt"
     empty.write_bytes(b"")
     assert W.linear.encode(str(empty), str(tmp_path / "missing_vocab.txt")) == []  # nothing to encode, nothing loaded
+
+
+def test_stats_struct_matches_header():
+    """The ctypes mirror of wp_stats (field order, widths, the array) follows include/wordpiece_amd.h, and the
+    option numbers of the Python module are the header's."""
+    import ctypes as C
+    import re
+    hdr = open(os.path.join(ROOT, "include", "wordpiece_amd.h")).read()
+    body = hdr[hdr.index("typedef struct {", hdr.index("statistics of the last encode")):hdr.index("} wp_stats;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.replace("typedef struct {", "").strip()
+        if not decl:
+            continue
+        ctype, names = decl.split(None, 1)
+        for name in names.split(","):
+            name = name.strip()
+            m = re.match(r"(\w+)\[(\d+)\]", name)
+            fields.append((m.group(1), ctype, int(m.group(2))) if m else (name, ctype, 0))
+    widths = {"int64_t": C.c_int64, "int32_t": C.c_int32, "double": C.c_double}
+    mirror = W.Stats._fields_
+    assert [f[0] for f in fields] == [f[0] for f in mirror]
+    for (name, ctype, count), (_, pytype) in zip(fields, mirror):
+        want = widths[ctype] * count if count else widths[ctype]
+        assert C.sizeof(pytype) == C.sizeof(want), name
+    for name, value in re.findall(r"#define (WP_OPT_\w+) (\d+)", hdr):
+        assert getattr(W, name) == int(value), name
