@@ -77,6 +77,45 @@ def _cpu_baseline(text, vocab, target_bytes):
                          else "the oracle's own prefix-doubling sorter")}, ids
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as children
+    (`python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`, the driver's own form),
+    relay rank 0's single JSON line and fail unless all N ranks took part.  The reference's precedent for fanning
+    out inside one call is linear.cpp:283-299.  Runs before this process makes any GPU call and never exec()s."""
+    import socket
+    import subprocess
+
+    backend = os.environ.get("WP_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    if backend == "nccl" and have < n:
+        print("bench.py: --gpus %d but only %d GPU(s) visible (WP_BENCH_BACKEND=gloo rehearses with shared devices)"
+              % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)  # anything else a child wrote to stdout
+    if r.returncode != 0 or line is None:
+        print("bench.py: the %d-rank run failed (exit code %d)" % (n, r.returncode), file=sys.stderr)
+        return r.returncode or 1
+    got = json.loads(line).get("n_gpus")
+    if got != n:
+        print("bench.py: %d rank(s) reported, %d asked for" % (got, n), file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,11 +132,17 @@ def main():
     ap.add_argument("--vocab-file", default=None)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it has not touched the GPU and
+        # never will), N fresh ranks do the work — never a silent single-GPU run under an N-GPU label
+        raise SystemExit(_self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if torch.cuda.device_count() == 0:  # (counting devices does not initialise the GPU: the corpus workers fork below)
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
 
     # ---- workload: one shard per rank (generated before the GPU is touched: worker processes) ----
     kind, mb_default, vs_default, wl_fmt = CONFIGS[args.config]
@@ -173,13 +218,18 @@ def main():
         from wordpiece_amd.gather import IdGather
         gather = IdGather(dist, rank, world, cdev)
 
+    steps_done = [0]
+
     def step():
         d_ids, n_ids = vocab_h.encode_device(d_text.data_ptr(), nbytes)
         if distributed:
             view = (torch.as_tensor(_DevView(d_ids, n_ids), device=dev) if n_ids
                     else torch.zeros(0, dtype=torch.int32, device=dev))
-            # the ids must be out of the handle's buffer before the next encode overwrites it
-            gather.step(view, n_ids, before_collective=torch.cuda.current_stream().synchronize)
+            # the ids must be out of the handle's buffer before the next encode overwrites it; every step encodes
+            # the same shard, so after the first one the counts are known and nothing is read back from the device
+            gather.step(view, n_ids, before_collective=torch.cuda.current_stream().synchronize,
+                        counts_known=steps_done[0] > 0)
+        steps_done[0] += 1
         return n_ids
 
     def fence():

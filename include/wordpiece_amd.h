@@ -13,7 +13,9 @@
  * reference is effectively single-caller too: its global thread pool barrier
  * waits on all tasks, utils.cpp:25-28).  The library needs a HIP device: there
  * is NO CPU fallback — without a GPU every compute entry point fails loudly
- * with WP_ERR_NO_DEVICE.
+ * with WP_ERR_NO_DEVICE.  No exception crosses the ABI, and every entry point leaves
+ * the calling thread's current HIP device as it found it (hipGetDevice on entry,
+ * hipSetDevice back on exit), whatever device the handle or its shards live on.
  */
 #ifndef WORDPIECE_AMD_H
 #define WORDPIECE_AMD_H
@@ -80,6 +82,16 @@ int wp_linear_encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const i
 /* Sizes the handle's device arenas and host staging for inputs of up to `nbytes`, so that the
  * first encode does not pay for the allocations (about 100 bytes of HBM per input symbol). */
 int wp_reserve(wp_vocab *v, size_t nbytes);
+
+/* Memory the library keeps between calls, and how to get it back.  A handle keeps its device arenas (about
+ * 100 bytes of HBM per input symbol of its largest encode) until it is destroyed.  A destroyed handle's
+ * context (streams, events, code tables) is parked in a process-wide pool of at most 4 for the next handle on
+ * the same device — the reference's API is one-shot, linear.cpp:332-335, and sets everything up per call —
+ * but only with arenas of up to 256 MB in total: larger ones are released at wp_vocab_destroy.  Returned id
+ * blocks are page-locked host memory; wp_free keeps up to 4 of them (6 GB) for reuse.
+ * wp_trim releases all of that: the arenas of `v`'s contexts (v may be NULL), the parked contexts' arenas and
+ * the pooled id blocks.  (Env WP_NO_CONTEXT_POOL=1 switches the context pool off.) */
+int wp_trim(wp_vocab *v);
 
 /* replaces word_piece::linear::encode(text_file, vocab_file)   word_piece.hpp:14, linear.cpp:337-341 */
 int wp_linear_encode_file(const char *text_file, const char *vocab_file, int32_t **ids,

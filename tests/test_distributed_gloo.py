@@ -23,6 +23,11 @@ def gather_ids(ids, rank, world, device="cpu"):
     t = torch.as_tensor(np.ascontiguousarray(ids), dtype=torch.int32)
     g.step(t, len(ids))
     g.step(t, len(ids))
+    g.step(t, len(ids), counts_known=True)  # bench.py's steady state: no count exchange, no read-back
+    if world > 1 and rank == world - 1 and len(ids) > 1:
+        # a changed count under counts_known must raise, never post a transfer of the wrong size
+        with pytest.raises(RuntimeError, match="count changed"):
+            g.step(t[:-1], len(ids) - 1, counts_known=True)
     return g.result()
 
 
@@ -51,3 +56,29 @@ def test_sharded_gather_equals_unsharded(tmp_path, world):
     out = str(tmp_path / "ids.npy")
     mp.spawn(_worker, args=(world, port, text, vocab, out), nprocs=world, join=True)
     assert np.array_equal(np.load(out), O.Vocab(vocab).encode(text))
+
+
+def _run_bench(args, env_extra, timeout=600):
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True,
+                          env=env, timeout=timeout)
+
+
+def test_bench_gpus_n_never_runs_as_one_rank():
+    """`python bench.py --gpus N` without a launcher starts the N ranks itself (the reference fans out
+    inside the call too, linear.cpp:283-299) and fails loudly when it cannot — it never prints a line measured
+    on one GPU.  Without a GPU (this test-suite's CPU leg) every form must exit non-zero and print no JSON."""
+    if torch.cuda.device_count() > 0:
+        pytest.skip("CPU leg: the launcher's success path is test_gpu_api.py::test_bench_self_launch_two_ranks")
+    r = _run_bench(["--gpus", "2", "--mb", "1"], {})  # backend nccl: not enough GPUs
+    assert r.returncode == 2 and "only 0 GPU(s) visible" in r.stderr and r.stdout.strip() == ""
+    r = _run_bench(["--gpus", "2", "--mb", "1"], {"WP_BENCH_BACKEND": "gloo"})  # two ranks start, none finds a GPU
+    assert r.returncode != 0 and "the 2-rank run failed" in r.stderr and r.stdout.strip() == ""
+    assert "bench.py needs an MI355X" in r.stderr  # a rank came up and said so (the launcher stops the other one)
+    r = _run_bench(["--gpus", "2", "--mb", "1"], {"WORLD_SIZE": "1", "RANK": "0"})  # a launcher with the wrong size
+    assert r.returncode != 0 and "WORLD_SIZE 1 != --gpus 2" in r.stderr

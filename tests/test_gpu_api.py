@@ -146,7 +146,10 @@ def test_encode_multi_same_gpu_contexts(corpus):
         assert st["n_devices"] == len(devs) and st["n_bytes"] == len(text) and st["n_ids"] == len(exp)
     assert np.array_equal(gv.encode_multi(text, None), exp)       # all visible GPUs
     assert len(gv.encode_multi(b"", [0, 0])) == 0
-    assert np.array_equal(gv.encode_multi(b"ab", [0, 0, 0]), O.Vocab(vocab).encode(b"ab"))  # empty shards
+    exp_ab = O.Vocab(vocab).encode(b"ab")
+    for _ in range(25):  # empty shards: no worker thread, no context for a shard without bytes
+        assert np.array_equal(gv.encode_multi(b"ab", [0, 0, 0]), exp_ab)
+        assert np.array_equal(gv.encode_multi(b"ab cd", [0, 0, 0, 0]), O.Vocab(vocab).encode(b"ab cd"))
     # mixed scripts: the cut positions follow the code points, not the bytes
     mixed = ("привет мир " * 40000).encode() + text[:400_000] + ("中文 分词 " * 30000).encode()
     assert np.array_equal(gv.encode_multi(mixed, [0, 0]), O.Vocab(vocab).encode(mixed))
@@ -195,15 +198,82 @@ def test_arena_guard_zones_intact(corpus):
                 assert np.array_equal(ids, O.Vocab(vc).encode(t))
 
 
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: two ranks are started by bench.py itself, rank 0's line
+    says n_gpus 2 and names the id gather (gloo rehearsal on this one-GPU box: the ranks share the device)."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WP_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mb", "8", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["id_gather"].startswith("gloo") and out["value"] > 0
+
+
+def test_calls_keep_the_current_device_and_trim_releases(corpus):
+    """Every entry point of the C ABI leaves the calling thread's current HIP device as it found it (a handle on
+    another GPU, wp_linear_encode_multi and wp_vocab_destroy all switch devices inside), and wp_trim gives the
+    arenas back.  With one GPU the handle lives on device 0 as well; on a multi-GPU box it is put on the last one."""
+    import ctypes as C
+    import torch
+    _, _, text, vocab, _ = corpus
+    W.lib()
+    try:  # the HIP runtime the library itself is linked against (by soname: the copy that is already loaded)
+        hip = C.CDLL("libamdhip64.so.7")
+    except OSError:
+        hip = C.CDLL("libamdhip64.so")
+
+    def current():
+        d = C.c_int(-1)
+        assert hip.hipGetDevice(C.byref(d)) == 0
+        return d.value
+
+    ndev = W.lib().wp_device_count()
+    assert ndev >= 1
+    assert hip.hipSetDevice(0) == 0
+    other = ndev - 1
+    exp = O.Vocab(vocab).encode(text)
+    gv = W.Vocab(vocab, device=other)
+    free0 = torch.cuda.mem_get_info(other)[0]
+    assert np.array_equal(gv.encode(text), exp) and current() == 0
+    assert np.array_equal(gv.fast_encode(text), O.Vocab(vocab).fast_encode(text)) and current() == 0
+    assert np.array_equal(gv.encode_multi(text, list(range(ndev)) + [other]), exp) and current() == 0
+    gv.reserve(1 << 24)
+    assert current() == 0
+    used = free0 - torch.cuda.mem_get_info(other)[0]
+    assert used > (100 << 20)          # the arenas of a 16 MB reserve
+    gv.trim()
+    assert current() == 0
+    assert free0 - torch.cuda.mem_get_info(other)[0] < used // 4
+    assert np.array_equal(gv.encode(text), exp)      # the next encode allocates again
+    del gv                                           # wp_vocab_destroy parks the contexts (hipSetDevice inside)
+    import gc
+    gc.collect()
+    assert current() == 0
+    W.lib().wp_trim(None)
+    assert current() == 0
+
+
 def test_symbol_limit_is_on_code_points():
     """linear.cpp:104-106 limits total_length (code points + vocab symbols), not bytes: 2.1 GB of ASCII is
     "64bit not implemented"; 2.1 GB of three-byte characters (0.7e9 code points) is encoded."""
     vocab = ["ab", "##c", "中", "文", "[UNK]"]
     gv = W.Vocab(vocab)
     unit = b"abc abd " * 1024
-    big = unit * (2_100_000_000 // len(unit) + 1)
+    big = unit * (2_200_000_000 // len(unit) + 1)
     with pytest.raises(W.WordPieceError, match="64bit not implemented"):
         gv.encode(big)
+    # the fast path's positions are 32-bit with bit 31 as the skip flag of its sparse walk: 2^31 code points or more
+    # are refused as well (fast.cpp has no limit of its own; never silent truncation)
+    with pytest.raises(W.WordPieceError, match="64bit not implemented"):
+        gv.fast_encode(big)
     del big
     unit = "中文 中 文x ".encode() * 1024
     reps = 2_100_000_000 // len(unit) + 1

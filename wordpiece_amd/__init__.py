@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "wp_linear_encode_device", "wp_linear_encode_file", "wp_linear_encode_external", "wp_set_option",
     "wp_get_stats", "wp_linear_debug_fetch", "wp_free", "wp_last_error", "wp_device_count",
     "wp_linear_encode_multi", "wp_reserve", "wp_fast_encode", "wp_fast_encode_device", "wp_fast_encode_file",
-    "wp_fast_encode_external", "wp_vocab_token_utf8",
+    "wp_fast_encode_external", "wp_vocab_token_utf8", "wp_trim",
 ]
 
 
@@ -89,6 +89,7 @@ def lib():
         L.wp_linear_encode_multi.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.POINTER(i32p),
                                              C.POINTER(C.c_size_t)]
         L.wp_reserve.argtypes = [vp, C.c_size_t]
+        L.wp_trim.argtypes = [vp]
         L.wp_fast_encode.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32p), C.POINTER(C.c_size_t)]
         L.wp_fast_encode_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.wp_fast_encode_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(i32p), C.POINTER(C.c_size_t)]
@@ -209,6 +210,10 @@ class Vocab:
     def reserve(self, nbytes):
         """Pre-sizes the device arenas and host staging for inputs of up to nbytes (wp_reserve)."""
         _check(lib().wp_reserve(self._h, int(nbytes)))
+
+    def trim(self):
+        """Releases this handle's device arenas, the parked contexts' arenas and the pooled id blocks (wp_trim)."""
+        _check(lib().wp_trim(self._h))
 
     def encode_device(self, d_ptr, nbytes):
         """Text already in HBM at `d_ptr` -> (device pointer of int32 ids, count).  The id buffer is

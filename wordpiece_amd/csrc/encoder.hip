@@ -177,6 +177,24 @@ struct Context {
     int32_t *best_scratch = nullptr;  // room for 2n int32 (debug expansion of the step functions)
     size_t n = 0, n_text = 0;
   } dbg;
+  Context() = default;
+  Context(const Context &) = delete;
+  Context &operator=(const Context &) = delete;
+  ~Context();  // releases whatever was built (a half-built context of a failed make_context included)
+};
+
+// The calling thread's current HIP device, put back when the scope ends: no entry point of the C ABI leaves the
+// caller on another device than it came in with (a host process — PyTorch, say — keeps allocating on "its" GPU).
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
 }  // namespace wp
@@ -210,30 +228,43 @@ static void free_vocab_tables(Context *c) {
   }
 }
 
+// idempotent: every resource is cleared as it is released (runs from ~Context too)
 static void destroy_context(Context *c) {
   if (!c) return;
+  const bool owns = c->stream || c->stream2 || c->d_used || c->d_lut || c->d_scan_tmp || c->d_scalars || c->d_code ||
+                    c->d_symhist || c->h_scalars || c->h_code || c->d_stream || c->text_buf.p || c->a_buf.p ||
+                    c->b_buf.p || c->fmt_buf.p;
+  if (!owns) return;
+  DeviceGuard keep;
   (void)hipSetDevice(c->device);
   free_vocab_tables(c);
-  for (void *p : {static_cast<void *>(c->d_used), static_cast<void *>(c->d_lut), static_cast<void *>(c->d_scan_tmp),
-                  static_cast<void *>(c->d_scalars), static_cast<void *>(c->d_code),
-                  static_cast<void *>(c->d_symhist)}) {
-    if (p) (void)hipFree(p);
+  for (void **p : {reinterpret_cast<void **>(&c->d_used), reinterpret_cast<void **>(&c->d_lut),
+                   reinterpret_cast<void **>(&c->d_scan_tmp), reinterpret_cast<void **>(&c->d_scalars),
+                   reinterpret_cast<void **>(&c->d_code), reinterpret_cast<void **>(&c->d_symhist)}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
   }
   if (c->h_scalars) (void)hipHostFree(c->h_scalars);
   if (c->h_code) (void)hipHostFree(c->h_code);
+  c->h_scalars = nullptr;
+  c->h_code = nullptr;
   c->text_buf.release();
   c->a_buf.release();
   c->b_buf.release();
   c->fmt_buf.release();
   for (auto &e : c->ev) {
     if (e) (void)hipEventDestroy(e);
+    e = nullptr;
   }
   for (auto &e : c->evs) {
     if (e) (void)hipEventDestroy(e);
+    e = nullptr;
   }
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  c->stream = c->stream2 = nullptr;
 }
+Context::~Context() { destroy_context(this); }
 
 template <typename T>
 static T *upload(const std::vector<T> &v, hipStream_t st) {
@@ -247,9 +278,11 @@ static T *upload(const std::vector<T> &v, hipStream_t st) {
 // sets everything up again (linear.cpp:332-341), and its test-suite does that tens of thousands of times.
 // Here a context (two streams, events, code point tables, scalars, the arenas) costs ~1.5 ms to make, so
 // the contexts of destroyed handles are parked in a small process-wide pool and the next handle on the
-// same device takes one over, replacing only the vocabulary tables.  Arenas above kPoolArenaBytes are
-// given back to the driver first (a parked context must not sit on 100 GB of HBM).
-static constexpr size_t kPoolArenaBytes = size_t(16) << 30;
+// same device takes one over, replacing only the vocabulary tables.  What a parked context keeps is SMALL
+// state: arenas of more than kPoolArenaBytes in total go back to the driver when the handle is destroyed (a
+// destroyed handle must not sit on the gigabytes its last encode needed — the pool exists for the sub-millisecond
+// one-shot calls on tiny inputs); wp_trim() releases the rest.
+static constexpr size_t kPoolArenaBytes = size_t(256) << 20;
 static constexpr size_t kPoolContexts = 4;
 static std::mutex g_pool_mu;
 static std::vector<std::unique_ptr<Context>> &context_pool() {
@@ -257,18 +290,23 @@ static std::vector<std::unique_ptr<Context>> &context_pool() {
   return *pool;
 }
 
+static void release_arenas(Context *c) {
+  c->text_buf.release();
+  c->a_buf.release();
+  c->b_buf.release();
+  c->fmt_buf.release();
+  c->d_ids = nullptr;
+  c->dbg = {};
+}
+
 static void park_context(std::unique_ptr<Context> c) {
   if (!c) return;
   static const bool no_pool = getenv("WP_NO_CONTEXT_POOL") && atoi(getenv("WP_NO_CONTEXT_POOL")) != 0;
+  DeviceGuard keep;
   (void)hipSetDevice(c->device);
   if (!no_pool && hipStreamSynchronize(c->stream) == hipSuccess && hipStreamSynchronize(c->stream2) == hipSuccess) {
     free_vocab_tables(c.get());
-    if (c->text_buf.cap + c->a_buf.cap + c->b_buf.cap + c->fmt_buf.cap > kPoolArenaBytes) {
-      c->text_buf.release();
-      c->a_buf.release();
-      c->b_buf.release();
-      c->fmt_buf.release();
-    }
+    if (c->text_buf.cap + c->a_buf.cap + c->b_buf.cap + c->fmt_buf.cap > kPoolArenaBytes) release_arenas(c.get());
     c->d_ids = nullptr;
     c->dbg = {};
     std::lock_guard<std::mutex> g(g_pool_mu);
@@ -323,15 +361,10 @@ static std::unique_ptr<Context> make_context(const wp_vocab *v, int device) {
     }
   }
   if (c) {
-    try {
-      upload_vocab_tables(c.get(), v->hv);
-    } catch (...) {
-      destroy_context(c.get());
-      throw;
-    }
+    upload_vocab_tables(c.get(), v->hv);  // (a throw destroys the context: ~Context)
     return c;
   }
-  c.reset(new Context());
+  c.reset(new Context());  // (a throwing WP_HIP below releases what was built so far: ~Context)
   c->device = device;
   WP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   WP_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -1298,7 +1331,9 @@ static void encode_fast_on_device(const wp_vocab *v, Context *c, const uint8_t *
   fetch_scalars(c, 16);
   unsigned long long n_text64;
   std::memcpy(&n_text64, c->h_scalars + 14, sizeof(n_text64));
-  if (n_text64 > 4000000000ull) throw std::length_error("text of more than 4e9 code points");  // 32-bit positions
+  // positions are 32-bit and bit 31 of an anchor entry is the skip flag of the sparse / long-word walk (walk.h,
+  // kAnchorSkip): the same kind of limit as linear.cpp:104-106, never silent truncation
+  if (n_text64 >= (1ull << 31)) throw std::length_error("64bit not implemented (fast path: text of 2^31 or more code points)");
   const size_t n_text = c->h_scalars[0];
   unsigned long long dropped;
   std::memcpy(&dropped, c->h_scalars + 2, sizeof(dropped));
@@ -1453,8 +1488,10 @@ wp_vocab::~wp_vocab() {
 // ======================================================================================
 // C ABI
 // ======================================================================================
+// Nothing leaves the C ABI as an exception, and the caller's current HIP device is the same after the call as before.
 template <typename F>
 static int guarded(F &&f) {
+  DeviceGuard keep_device;
   try {
     f();
     return WP_OK;
@@ -1473,6 +1510,9 @@ static int guarded(F &&f) {
   } catch (const std::exception &e) {
     g_last_error = e.what();
     return WP_ERR_HIP;
+  } catch (...) {
+    g_last_error = "unknown exception inside the HIP WordPiece library";
+    return WP_ERR_HIP;
   }
 }
 
@@ -1481,6 +1521,7 @@ static int vocab_from_lines(const std::vector<std::pair<const char *, size_t>> &
     g_last_error = "null output pointer";
     return WP_ERR_ARG;
   }
+  try {
   std::unique_ptr<wp_vocab> v(new wp_vocab());
   if (const char *e = getenv("WP_DEVICES")) {  // default of WP_OPT_DEVICES ("all" or a count): the C++ API has no handle to set it on
     v->n_devices = std::strcmp(e, "all") == 0 ? -1 : std::max(1, atoi(e));
@@ -1492,6 +1533,13 @@ static int vocab_from_lines(const std::vector<std::pair<const char *, size_t>> &
   }
   *out = v.release();
   return WP_OK;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return WP_ERR_ARG;
+  } catch (...) {
+    g_last_error = "unknown exception while building the vocabulary";
+    return WP_ERR_ARG;
+  }
 }
 
 extern "C" {
@@ -1521,7 +1569,13 @@ int wp_vocab_from_file(const char *vocab_file, wp_vocab **out) {
   return vocab_from_lines(ls, out);
 }
 
-void wp_vocab_destroy(wp_vocab *v) { delete v; }
+void wp_vocab_destroy(wp_vocab *v) {
+  if (!v) return;
+  try {
+    delete v;  // (parks the handle's contexts: park_context keeps the caller's current device)
+  } catch (...) {
+  }
+}
 int64_t wp_vocab_size(const wp_vocab *v) { return static_cast<int64_t>(v->hv.tokens.size()); }
 int32_t wp_vocab_unk_id(const wp_vocab *v) { return v->hv.unk_id; }
 int32_t wp_vocab_token_flags(const wp_vocab *v, int64_t i) {
@@ -1625,6 +1679,15 @@ struct PinnedPool {
     (void)hipHostFree(p);
     return true;
   }
+  void trim() {  // pooled (free) blocks go back to the driver
+    std::vector<std::pair<size_t, void *>> drop;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      drop.swap(pooled);
+      for (auto &b : drop) owned.erase(b.second);
+    }
+    for (auto &b : drop) (void)hipHostFree(b.second);
+  }
 };
 PinnedPool &id_pool() {
   static PinnedPool *pool = new PinnedPool();  // never destroyed: blocks may outlive static destruction order
@@ -1702,13 +1765,14 @@ void encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const std::vecto
                                                         : devices_in;
   const int G = static_cast<int>(devices.size());
   const auto t_all = wp_clock::now();
+  const std::vector<size_t> cuts = shard_cuts(utf8, nbytes, G);
   if (v->multi.size() < static_cast<size_t>(G)) v->multi.resize(static_cast<size_t>(G));
   for (int g = 0; g < G; g++) {  // (contexts are made on the calling thread: a failure here is a plain exception)
+    if (cuts[static_cast<size_t>(g)] == cuts[static_cast<size_t>(g) + 1]) continue;  // an empty shard needs none
     Context *c = v->multi[static_cast<size_t>(g)].get();
     if (c && c->device != devices[static_cast<size_t>(g)]) park_context(std::move(v->multi[static_cast<size_t>(g)]));
     if (!v->multi[static_cast<size_t>(g)]) v->multi[static_cast<size_t>(g)] = make_context(v, devices[static_cast<size_t>(g)]);
   }
-  const std::vector<size_t> cuts = shard_cuts(utf8, nbytes, G);
   std::vector<size_t> counts(static_cast<size_t>(G), 0);
   std::vector<wp_stats> stats(static_cast<size_t>(G));
   std::vector<std::string> errors(static_cast<size_t>(G));
@@ -1724,13 +1788,43 @@ void encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const std::vecto
       encode_on_device(v, c, static_cast<const uint8_t *>(c->text_buf.p), hi - lo, &counts[static_cast<size_t>(g)],
                        stats[static_cast<size_t>(g)]);
     });
-    if (codes[static_cast<size_t>(g)] != WP_OK) errors[static_cast<size_t>(g)] = g_last_error;
+    if (codes[static_cast<size_t>(g)] != WP_OK) {
+      try {
+        errors[static_cast<size_t>(g)] = g_last_error;
+      } catch (...) {  // (out of memory while copying the message: the code alone is reported)
+      }
+    }
   };
   {
-    std::vector<std::thread> threads;
-    for (int g = 1; g < G; g++) threads.emplace_back(work, g);
-    work(0);
-    for (auto &t : threads) t.join();
+    // Worker threads are joined on every way out of this scope (a std::thread that is still joinable when it is
+    // destroyed ends the process: std::terminate), work() itself cannot throw (everything that can sits inside
+    // guarded(), the error slots are sized up front), and a shard without bytes gets no thread at all.
+    struct Joiner {
+      std::vector<std::thread> threads;
+      ~Joiner() {
+        for (auto &t : threads) {
+          if (t.joinable()) t.join();
+        }
+      }
+    } pool;
+    pool.threads.reserve(static_cast<size_t>(G));
+    int own = -1;  // the first non-empty shard runs on the calling thread
+    for (int g = 0; g < G; g++) {
+      if (cuts[static_cast<size_t>(g)] == cuts[static_cast<size_t>(g) + 1]) {
+        std::memset(&stats[static_cast<size_t>(g)], 0, sizeof(wp_stats));
+        continue;
+      }
+      if (own < 0) {
+        own = g;
+        continue;
+      }
+      try {
+        pool.threads.emplace_back(work, g);
+      } catch (const std::exception &e) {  // (no thread to be had: the shard runs here, after the others were started)
+        work(g);
+      }
+    }
+    if (own >= 0) work(own);
   }
   for (int g = 0; g < G; g++) {
     if (codes[static_cast<size_t>(g)] == WP_OK) continue;
@@ -1758,6 +1852,7 @@ void encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const std::vecto
     }
     for (int g = 0; g < G; g++) {
       Context *c = v->multi[static_cast<size_t>(g)].get();
+      if (!counts[static_cast<size_t>(g)]) continue;
       WP_HIP(hipSetDevice(c->device));
       WP_HIP(hipStreamSynchronize(c->stream));
     }
@@ -1867,6 +1962,29 @@ int wp_reserve(wp_vocab *v, size_t nbytes) {
     c->a_buf.ensure(nbytes + nbytes / 512 + (size_t(1) << 20) + (v->keep_debug ? 4 * nbytes : 0));
     c->b_buf.ensure(108 * n + (v->keep_debug ? 4 * n : 0) + (size_t(64) << 20));
     PinnedBlock warm(nbytes + (size_t(1) << 20));  // about a quarter of an id per byte, 4 bytes each
+  });
+}
+
+// Gives cached memory back to the driver: the device arenas of this handle's contexts (v may be NULL), the arenas
+// of the parked contexts of destroyed handles, and the pooled pinned id blocks.  The next encode allocates again.
+int wp_trim(wp_vocab *v) {
+  return guarded([&] {
+    auto drop = [](Context *c) {
+      if (!c) return;
+      WP_HIP(hipSetDevice(c->device));
+      WP_HIP(hipStreamSynchronize(c->stream));
+      WP_HIP(hipStreamSynchronize(c->stream2));
+      release_arenas(c);
+    };
+    if (v) {
+      drop(v->ctx.get());
+      for (auto &c : v->multi) drop(c.get());
+    }
+    {
+      std::lock_guard<std::mutex> g(g_pool_mu);
+      for (auto &c : context_pool()) drop(c.get());
+    }
+    id_pool().trim();
   });
 }
 

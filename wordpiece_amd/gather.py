@@ -19,19 +19,30 @@ class IdGather:
         self.buf = None     # rank 0: all ids in shard order
         self.send = None    # other ranks: staging copy of the own ids (the encoder reuses its buffer)
         self.host_counts = [0] * world
+        self.primed = False  # host_counts hold the counts of a step
 
     def _room(self, t, n):
         if t is None or t.numel() < n:
             t = torch.empty(int(n * 1.05) + 1024, dtype=torch.int32, device=self.device)
         return t
 
-    def step(self, ids, n_ids, before_collective=None):
+    def step(self, ids, n_ids, before_collective=None, counts_known=False):
         """ids: int32 tensor (any device) holding n_ids ids.  before_collective(): called after the ids
-        have been copied out of `ids` (bench.py synchronises there, because the encoder reuses the buffer)."""
+        have been copied out of `ids` (bench.py synchronises there, because the encoder reuses the buffer).
+        counts_known: EVERY rank promises that its count is the one of the previous step (the same shard encoded
+        again): the count exchange and its read-back — a host sync per step — are skipped and the receives are
+        posted with the sizes already known.  A rank whose count did change raises instead of posting a receive
+        of the wrong size (the decision has to be the same on all ranks, so there is no silent fallback)."""
         dist = self.dist
-        self.cnt.fill_(n_ids)
-        dist.all_gather(self.counts, self.cnt)
-        self.host_counts = [int(c.item()) for c in self.counts]
+        if counts_known and self.primed:
+            if n_ids != self.host_counts[self.rank]:
+                raise RuntimeError("IdGather: counts_known, but this rank's count changed (%d -> %d)"
+                                   % (self.host_counts[self.rank], n_ids))
+        else:
+            self.cnt.fill_(n_ids)
+            dist.all_gather(self.counts, self.cnt)
+            self.host_counts = [int(c) for c in torch.cat(self.counts).tolist()]  # one read-back for all counts
+            self.primed = True
         if self.rank == 0:
             total = sum(self.host_counts)
             self.buf = self._room(self.buf, total)
