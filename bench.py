@@ -31,7 +31,8 @@ import torch  # noqa: E402
 import wordpiece_amd as W  # noqa: E402
 from wordpiece_amd import synth  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBPS = 6300.0  # what plain read / copy kernels reach on this GPU (guide: ~6.3; profiles/r01_hbm_probe.txt: 6.25 / 5.73)
 # one radix pass reads and writes a (key, index) record: 12 bytes with a 64-bit key (round 1 of this
 # build), 8 bytes with the 32-bit round-0 keys of this round (wp_stats.key_bits); radix_bytes() below
 # SA/LCP stage, algorithmic bytes per symbol besides the radix passes:
@@ -40,6 +41,10 @@ SPLIT_BYTES = 12       # round 0 after the sort (round0_rank_kernel): keys 4 rea
 RANK_STORE_BYTES = 12  # window store: (destination, rank) 8 read, rank 4 written; the one or two partition passes in
                        # front of it are full-size launches of the radix scatter (16 B per element, counted there)
 ROUND_BYTES = 110      # rounds >= 1, per list entry: LDS sort 28 + split 50 + rank store 32
+
+# In-container calibration of the CPU port against the compiled reference (filled in from
+# DESIGN.md section 4): same config-2 synthetic, 8 vCPUs of the build container.
+CPU_CALIBRATION = "TBD"
 
 _DevView = W.DeviceIds  # zero-copy torch view of a device buffer owned by the library
 
@@ -51,30 +56,67 @@ CONFIGS = {
 }
 
 
+def _host_cpu():
+    """CPU model string, physical cores and logical CPUs of the box (Linux /proc/cpuinfo), and the CPUs this
+    process may run on."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        with open("/proc/cpuinfo") as f:
+            pid = None
+            for ln in f:
+                k, _, v = ln.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name" and model == "unknown":
+                    model = v
+                elif k == "processor":
+                    logical += 1
+                elif k == "physical id":
+                    pid = v
+                elif k == "core id":
+                    phys.add((pid, v))
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return model, (len(phys) or logical or usable), (logical or usable), usable
+
+
 def _cpu_baseline(text, vocab, target_bytes):
     """The CPU port (oracle/, OpenMP; SA stage through the reference's own libsais when oracle/_ref
-    was built) timed on a bounded sample of the same workload."""
+    was built) timed on bounded samples of the same workload, as SURVEY 8(d) asks: all physical cores the
+    process may use (capped at 64: a 64 MB sample gives more threads nothing to do) and one thread, CPU model
+    and core counts stated."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
-    cut = min(len(text), target_bytes)
-    while cut < len(text) and text[cut] not in b" \n":
-        cut += 1
-    sample = text[:cut]
+    def sample_of(nbytes):
+        cut = min(len(text), int(nbytes))
+        while cut < len(text) and text[cut] not in b" \n":
+            cut += 1
+        return text[:cut]
+
+    model, phys, logical, usable = _host_cpu()
+    threads = max(1, min(phys, usable, 64))
+    sample = sample_of(target_bytes)
+    one = sample_of(max(target_bytes / 8, 2e6))
     used_ref_sa = O.use_libsais(True)
-    cores = os.cpu_count() or 1
     try:
         ov = O.Vocab(vocab)
         t0 = time.time()
-        ids = ov.encode(sample, threads=cores)
+        ids = ov.encode(sample, threads=threads)
         dt = time.time() - t0
+        t0 = time.time()
+        ids1 = ov.encode(one, threads=1)
+        dt1 = time.time() - t0
     finally:
         O.use_libsais(False)
-    return {"value": round(len(sample) / 1e6 / dt, 3), "unit": "MB/s", "cores": cores, "kind": "port",
-            "sample": "first %.1f MB of the rank-0 shard, %d ids, %.1f s; oracle/wp_oracle.c with OpenMP, SA stage via %s"
-                      % (len(sample) / 1e6, len(ids), dt,
-                         "the reference's libsais built from source (oracle/_ref)" if used_ref_sa
-                         else "the oracle's own prefix-doubling sorter")}, ids
+    sa = "the reference's libsais built from source (oracle/_ref)" if used_ref_sa else "the oracle's own prefix-doubling sorter"
+    return {"value": round(len(sample) / 1e6 / dt, 3), "unit": "MB/s", "cores": threads, "kind": "port",
+            "sample": "first %.1f MB of the rank-0 shard, %d ids, %.1f s on %d threads; oracle/wp_oracle.c with OpenMP, SA stage via %s"
+                      % (len(sample) / 1e6, len(ids), dt, threads, sa),
+            "single_thread": {"value": round(len(one) / 1e6 / dt1, 3), "unit": "MB/s", "cores": 1,
+                              "sample": "first %.1f MB, %d ids, %.1f s" % (len(one) / 1e6, len(ids1), dt1)},
+            "cpu_model": model, "physical_cores": phys, "logical_cpus": logical, "usable_cpus": usable,
+            "calibration": CPU_CALIBRATION}, ids
 
 
 def _self_launch(n):
@@ -125,7 +167,7 @@ def main():
     ap.add_argument("--mb", type=float, default=None, help="shard size per GPU in MB (1 MB = 1e6 bytes); default: the configuration's")
     ap.add_argument("--vocab-size", type=int, default=None)
     ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--cpu-sample-mb", type=float, default=32.0)
+    ap.add_argument("--cpu-sample-mb", type=float, default=64.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-to-host and fast-path measurements")
     ap.add_argument("--text-file", default=None, help="optional local corpus instead of the synthetic shard")
@@ -309,7 +351,8 @@ def main():
                        "id_gather": ("%s: exact-size receives on rank 0" % ("rccl" if backend == "nccl" else backend)) if distributed
                        else "none (single GPU)"},
             "roofline": {"bound": "hbm", "kernel": scatter_name, "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "peak": HBM_PEAK_GBPS, "achievable": HBM_ACHIEVABLE_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBPS, 4),
                          "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 4),
                          "algorithmic_bytes_per_launch": int(avg_launch_bytes)},
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage_ms.items()},

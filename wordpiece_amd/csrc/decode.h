@@ -11,199 +11,514 @@
 
 namespace wp {
 
-constexpr int kDecBytes = 16;
-constexpr int kDecTile = kBlock * kDecBytes;  // 4096 input bytes per workgroup
-constexpr uint32_t kCpTableSize = 0x110000;   // used[] / lut[] cover every code point
+// ---- layout of the two UTF-8 passes -------------------------------------------------------------------------
+// A wave owns kDecRows rows of 1 KB: lane l of row r holds the 16 bytes at row base + 16 l, so every row is one
+// fully coalesced 16-byte-per-lane load and all rows of a wave are in flight before anything is used.  A
+// workgroup (4 waves) covers 16 KB of input with ONE block-wide prefix step.  Bytes are tested as 32-bit words
+// (SWAR): a word of pure ASCII is one mask test, and the structure of multi-byte sequences — lead classes,
+// continuation bytes behind them, overlong forms, surrogates, > U+10FFFF — is evaluated for the four byte positions
+// of a word at once from the word and its three byte-shifted successors (v_alignbyte), no per-byte unpacking.
+constexpr int kDecChunk = 16;                               // bytes per lane and row
+constexpr int kDecRows = 4;                                 // rows per wave
+constexpr int kDecRowBytes = kWave * kDecChunk;             // 1 KB
+constexpr int kDecWaveBytes = kDecRowBytes * kDecRows;      // 4 KB
+constexpr int kDecTile = (kBlock / kWave) * kDecWaveBytes;  // 16 KB of input per workgroup
+constexpr uint32_t kCpTableSize = 0x110000;                 // lut[] covers every code point
+constexpr uint32_t kCpWords = kCpTableSize / 32;            // the used-code-point bitmap
+constexpr uint32_t kHi = 0x80808080u;
 
-// loads this thread's 16 bytes + 4 halo bytes into b[20] (zero padded past nbytes)
-__device__ __forceinline__ void load_bytes20(const uint8_t *__restrict__ text, size_t nbytes, size_t off,
-                                             uint8_t (&b)[20]) {
-  uint32_t w[5];
-  const size_t nwords = (nbytes + 3) / 4;  // the buffer is allocated padded to 16 bytes
-  const uint32_t *t32 = reinterpret_cast<const uint32_t *>(text);
-#pragma unroll
-  for (int k = 0; k < 5; k++) {
-    size_t wi = off / 4 + k;
-    w[k] = wi < nwords ? t32[wi] : 0u;
-  }
-#pragma unroll
-  for (int k = 0; k < 20; k++) {
-    uint32_t v = (w[k / 4] >> (8 * (k % 4))) & 0xffu;
-    b[k] = (off + k < nbytes) ? static_cast<uint8_t>(v) : 0;
-  }
+// per byte position of a word (bit 7 of byte j): does a valid 1 / 2 / 3 / 4-byte sequence start here?
+// Same verdicts as decode_one (utf8.cpp:54-90): w0 = the word, nx = the four bytes behind it.
+struct Utf8Starts {
+  uint32_t v1, v2, v3, v4;
+};
+__device__ __forceinline__ Utf8Starts utf8_starts(uint32_t w0, uint32_t nx) {
+  const uint32_t w1 = __builtin_amdgcn_alignbyte(nx, w0, 1);  // byte j of w1 = the byte behind byte j of w0
+  const uint32_t w2 = __builtin_amdgcn_alignbyte(nx, w0, 2);
+  const uint32_t w3 = __builtin_amdgcn_alignbyte(nx, w0, 3);
+  auto cont = [](uint32_t x) { return x & ~(x << 1) & kHi; };  // 10xxxxxx
+  const uint32_t c1 = cont(w1), c2 = cont(w2), c3 = cont(w3);
+  const uint32_t s1 = w0 << 1, s2 = w0 << 2, s3 = w0 << 3, s4 = w0 << 4;  // bit 7 of a byte <- its bit 6 / 5 / 4 / 3
+  const uint32_t l2 = w0 & s1 & ~s2 & kHi;                                  // 110xxxxx
+  const uint32_t l3 = w0 & s1 & s2 & ~s3 & kHi;                             // 1110xxxx
+  const uint32_t l4 = w0 & s1 & s2 & s3 & ~s4 & kHi;                        // 11110xxx
+  auto byte_zero = [](uint32_t x) { return ~(x + 0x7f7f7f7fu) & kHi; };     // (bytes of x <= 0x7f: no carries)
+  const uint32_t over2 = byte_zero(w0 & 0x1e1e1e1eu);                       // C0, C1: code point < 0x80
+  const uint32_t lo4 = w0 & 0x0f0f0f0fu;
+  const uint32_t n5 = w1 << 2;                                              // bit 5 of the next byte
+  // E0 80..9F: code point < 0x800; ED A0..BF: surrogates
+  const uint32_t bad3 = (byte_zero(lo4) & ~n5) | (byte_zero(lo4 ^ 0x0d0d0d0du) & n5);
+  const uint32_t lo3 = w0 & 0x07070707u;
+  const uint32_t n54 = (w1 << 2) | (w1 << 3);                               // next byte >= 0x90 (a continuation byte)
+  // F0 80..8F: code point < 0x10000; F4 90..: > U+10FFFF; F5..F7
+  const uint32_t bad4 = (byte_zero(lo3) & ~n54) | (byte_zero(lo3 ^ 0x04040404u) & n54) | ((w0 << 5) & ((w0 << 6) | (w0 << 7)));
+  Utf8Starts r;
+  r.v1 = ~w0 & kHi;
+  r.v2 = l2 & c1 & ~over2;
+  r.v3 = l3 & c1 & c2 & ~bad3 & kHi;
+  r.v4 = l4 & c1 & c2 & c3 & ~bad4 & kHi;
+  return r;
+}
+// the code point of a VALID sequence: x = the four bytes from its lead on
+__device__ __forceinline__ uint32_t utf8_value(uint32_t x) {
+  const uint32_t b0 = x & 0xffu, b1 = (x >> 8) & 0x3fu, b2 = (x >> 16) & 0x3fu, b3 = (x >> 24) & 0x3fu;
+  if (b0 < 0x80u) return b0;
+  if (b0 < 0xe0u) return ((b0 & 0x1fu) << 6) | b1;
+  if (b0 < 0xf0u) return ((b0 & 0x0fu) << 12) | (b1 << 6) | b2;
+  return ((b0 & 0x07u) << 18) | (b1 << 12) | (b2 << 6) | b3;
+}
+// bit 7 of byte j -> bit j
+__device__ __forceinline__ uint32_t byte_mask4(uint32_t m) {
+  const uint32_t x = m >> 7;
+  return (x | (x >> 7) | (x >> 14) | (x >> 21)) & 0xfu;
 }
 
-// pass 1: number of valid code points per tile, and the number of input bytes no code point consumes
-// (dropped != 0  <=>  the reference would print its invalid-unicode warning, utf8.cpp:143-145)
+// The rows of a wave: w[r][0..3] = the lane's 16 bytes of row r, w[r][4] = the four bytes behind them.  Bytes at or
+// behind nbytes read as zero (never a continuation byte: a sequence cut off by the end of the text is invalid, as
+// decode_one's size test has it).  text: 4-byte aligned, readable up to the next multiple of 16 behind nbytes.
+__device__ __forceinline__ void dec_load_rows(const uint8_t *__restrict__ text, size_t nbytes, size_t wave_base, int lane,
+                                              uint32_t (&w)[kDecRows][5]) {
+  const size_t padded = (nbytes + 15) & ~static_cast<size_t>(15);
+#pragma unroll
+  for (int r = 0; r < kDecRows; r++) {
+    const size_t off = wave_base + static_cast<size_t>(r) * kDecRowBytes + static_cast<size_t>(lane) * kDecChunk;
+    if (off < padded) {
+      const uint32_t *p = reinterpret_cast<const uint32_t *>(text + off);
+      w[r][0] = p[0];
+      w[r][1] = p[1];
+      w[r][2] = p[2];
+      w[r][3] = p[3];
+    } else {
+      w[r][0] = w[r][1] = w[r][2] = w[r][3] = 0u;
+    }
+  }
+  const size_t tail_off = wave_base + kDecWaveBytes;  // the word behind the wave's last row (one broadcast load)
+  const uint32_t tail = tail_off < padded ? *reinterpret_cast<const uint32_t *>(text + tail_off) : 0u;
+#pragma unroll
+  for (int r = 0; r < kDecRows; r++) {
+    const uint32_t from_next_lane = __shfl_down(w[r][0], 1, kWave);
+    const uint32_t next_row = r + 1 < kDecRows ? __shfl(w[r + 1 < kDecRows ? r + 1 : r][0], 0, kWave) : tail;
+    w[r][4] = lane == kWave - 1 ? next_row : from_next_lane;
+  }
+  if (wave_base + kDecWaveBytes + 4 > nbytes) {  // (wave-uniform: only the wave that holds the end of the text)
+#pragma unroll
+    for (int r = 0; r < kDecRows; r++) {
+      const size_t off = wave_base + static_cast<size_t>(r) * kDecRowBytes + static_cast<size_t>(lane) * kDecChunk;
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const size_t pos = off + 4 * static_cast<size_t>(k);
+        if (pos >= nbytes) {
+          w[r][k] = 0u;
+        } else if (pos + 4 > nbytes) {
+          w[r][k] &= (1u << (8 * static_cast<unsigned>(nbytes - pos))) - 1u;
+        }
+      }
+    }
+  }
+}
+// positions of the lane's chunk that lie inside the text, as a 16-bit mask (0xffff except at the very end)
+__device__ __forceinline__ uint32_t dec_inside16(size_t off, size_t nbytes) {
+  if (off + kDecChunk <= nbytes) return 0xffffu;
+  if (off >= nbytes) return 0u;
+  return (1u << static_cast<unsigned>(nbytes - off)) - 1u;
+}
+
+// pass 1: number of valid code points per tile, the number of input bytes no code point consumes
+// (dropped != 0  <=>  the reference would print its invalid-unicode warning, utf8.cpp:143-145), and — MARK — the
+// set of code points that occur, as a bitmap (used_bits, kCpWords words): ASCII through 128 flag words in LDS
+// (a plain store per byte), the rest of the BMP through an 8 KB LDS bitmap that the tile merges into the global
+// one (read first: once a code point is known, a tile only reads), astral code points directly.
+template <bool MARK>
 __global__ __launch_bounds__(kBlock) void decode_count_kernel(const uint8_t *__restrict__ text, size_t nbytes,
                                                               uint32_t *__restrict__ tile_counts,
                                                               unsigned long long *__restrict__ dropped,
-                                                              uint32_t *__restrict__ used) {
-  __shared__ uint32_t sm[8];
-  __shared__ uint32_t low_used[8];  // bitmap of code points < 256 seen by this tile
-  if (threadIdx.x < 8) low_used[threadIdx.x] = 0;
-  __syncthreads();
-  const size_t off = static_cast<size_t>(blockIdx.x) * kDecTile + static_cast<size_t>(threadIdx.x) * kDecBytes;
+                                                              uint32_t *__restrict__ used_bits) {
+  __shared__ uint32_t s_seen[128];   // ASCII code points seen by this tile (flag words: same-address stores merge)
+  __shared__ uint32_t s_bmp[2048];   // code points 0x80..0xffff seen by this tile
+  __shared__ uint32_t s_cnt[kBlock / kWave], s_use[kBlock / kWave], s_multi;
+  const int lane = lane_id(), wv = wave_id();
+  if (MARK) {
+    if (threadIdx.x < 128) s_seen[threadIdx.x] = 0u;
+#pragma unroll
+    for (int q = 0; q < 2048 / kBlock; q++) s_bmp[q * kBlock + threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_multi = 0u;
+    __syncthreads();
+  }
+  const size_t tile_base = static_cast<size_t>(blockIdx.x) * kDecTile;
+  const size_t wave_base = tile_base + static_cast<size_t>(wv) * kDecWaveBytes;
+  uint32_t w[kDecRows][5];
+  dec_load_rows(text, nbytes, wave_base, lane, w);
   uint32_t cnt = 0, used_bytes = 0;
-  if (off < nbytes) {
-    uint8_t b[20];
-    load_bytes20(text, nbytes, off, b);
-    bool ascii = off + kDecBytes <= nbytes;
+  bool multi = false;
 #pragma unroll
-    for (int j = 0; j < kDecBytes; j++) ascii = ascii && b[j] < 0x80;
+  for (int r = 0; r < kDecRows; r++) {
+    const size_t off = wave_base + static_cast<size_t>(r) * kDecRowBytes + static_cast<size_t>(lane) * kDecChunk;
+    const uint32_t inside = dec_inside16(off, nbytes);
+    if (inside == 0u) continue;
+    const bool ascii = ((w[r][0] | w[r][1] | w[r][2] | w[r][3]) & kHi) == 0u && inside == 0xffffu;
     if (ascii) {  // common case: 16 one-byte code points
-      cnt = kDecBytes;
-      used_bytes = kDecBytes;
-      uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;  // bits of the 128-entry ASCII part of the bitmap
+      cnt += kDecChunk;
+      used_bytes += kDecChunk;
+      if (MARK) {
 #pragma unroll
-      for (int j = 0; j < kDecBytes; j++) {
-        const uint32_t bit = 1u << (b[j] & 31);
-        const int wi = b[j] >> 5;
-        m0 |= wi == 0 ? bit : 0u;
-        m1 |= wi == 1 ? bit : 0u;
-        m2 |= wi == 2 ? bit : 0u;
-        m3 |= wi == 3 ? bit : 0u;
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) s_seen[(w[r][k] >> (8 * j)) & 0xffu] = 1u;
+        }
       }
-      if (m0 & ~low_used[0]) atomicOr(&low_used[0], m0);
-      if (m1 & ~low_used[1]) atomicOr(&low_used[1], m1);
-      if (m2 & ~low_used[2]) atomicOr(&low_used[2], m2);
-      if (m3 & ~low_used[3]) atomicOr(&low_used[3], m3);
-    } else {
+      continue;
+    }
 #pragma unroll
-      for (int j = 0; j < kDecBytes; j++) {
-        if (off + j < nbytes) {
-          if ((b[j] & 0xc0u) != 0x80u) {
-            uint32_t cp = decode_one(&b[j], static_cast<int64_t>(nbytes - (off + j)));
-            if (cp != kInvalidUnicode) {
-              cnt++;
-              used_bytes += cp < 0x80 ? 1 : cp < 0x800 ? 2 : cp < 0x10000 ? 3 : 4;
-              if (cp < 256) {
-                atomicOr(&low_used[cp >> 5], 1u << (cp & 31));
-              } else {
-                used[cp] = 1u;
-              }
-            }
+    for (int k = 0; k < 4; k++) {
+      const uint32_t in4 = (inside >> (4 * k)) & 0xfu;
+      if (in4 == 0u) continue;
+      const uint32_t in_bytes = ((in4 & 1u) << 7) | ((in4 & 2u) << 14) | ((in4 & 4u) << 21) | ((in4 & 8u) << 28);
+      Utf8Starts u = utf8_starts(w[r][k], w[r][k + 1]);
+      u.v1 &= in_bytes;
+      u.v2 &= in_bytes;
+      u.v3 &= in_bytes;
+      u.v4 &= in_bytes;
+      const uint32_t n1 = __popc(u.v1), n2 = __popc(u.v2), n3 = __popc(u.v3), n4 = __popc(u.v4);
+      cnt += n1 + n2 + n3 + n4;
+      used_bytes += n1 + 2 * n2 + 3 * n3 + 4 * n4;
+      if (MARK) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if ((u.v1 >> (8 * j + 7)) & 1u) s_seen[(w[r][k] >> (8 * j)) & 0xffu] = 1u;
+        }
+        uint32_t m = u.v2 | u.v3 | u.v4;
+        while (m) {
+          const int bit = __ffs(static_cast<int>(m)) - 1;  // 8 j + 7
+          m &= m - 1u;
+          const uint32_t cp = utf8_value(__builtin_amdgcn_alignbyte(w[r][k + 1], w[r][k], static_cast<uint32_t>(bit >> 3)));
+          const uint32_t b = 1u << (cp & 31u);
+          if (cp < 0x10000u) {
+            if (!(s_bmp[cp >> 5] & b)) atomicOr(&s_bmp[cp >> 5], b);
+            multi = true;
+          } else if (!(used_bits[cp >> 5] & b)) {
+            atomicOr(&used_bits[cp >> 5], b);
           }
         }
       }
     }
   }
-  uint32_t tot, tot_bytes;
-  (void)block_excl_sum(cnt, sm, tot);
-  (void)block_excl_sum(used_bytes, sm, tot_bytes);
+  cnt = wave_reduce_sum(cnt);
+  used_bytes = wave_reduce_sum(used_bytes);
+  if (lane == 0) {
+    s_cnt[wv] = cnt;
+    s_use[wv] = used_bytes;
+  }
+  if (MARK && multi) s_multi = 1u;
+  __syncthreads();
   if (threadIdx.x == 0) {
+    uint32_t tot = 0, tot_bytes = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / kWave; i++) {
+      tot += s_cnt[i];
+      tot_bytes += s_use[i];
+    }
     tile_counts[blockIdx.x] = tot;
-    // bytes of this tile that no code point consumed; clean input never touches the counter (one
-    // same-address atomic per tile costs more than the whole pass)
-    const size_t t0 = static_cast<size_t>(blockIdx.x) * kDecTile;
-    const uint32_t tile_bytes = static_cast<uint32_t>(min(static_cast<size_t>(kDecTile), nbytes - t0));
+    // bytes of this tile that no code point consumed; clean input never touches the counter
+    const uint32_t tile_bytes = static_cast<uint32_t>(min(static_cast<size_t>(kDecTile), nbytes - tile_base));
     if (tot_bytes != tile_bytes) {
       atomicAdd(dropped, static_cast<unsigned long long>(tile_bytes) - static_cast<unsigned long long>(tot_bytes));
     }
   }
-  if ((low_used[threadIdx.x >> 5] >> (threadIdx.x & 31)) & 1u) used[threadIdx.x] = 1u;
+  if (MARK) {
+    if (threadIdx.x < 128) {  // waves 0 and 1: the ASCII flags as two bitmap words each
+      const uint64_t m = __ballot(s_seen[threadIdx.x] != 0u);
+      if (lane < 2) {
+        const uint32_t bits = static_cast<uint32_t>(m >> (32 * lane));
+        uint32_t *dst = used_bits + 2 * wv + lane;
+        if (bits && (*dst & bits) != bits) atomicOr(dst, bits);
+      }
+    }
+    if (s_multi) {
+#pragma unroll
+      for (int q = 0; q < 2048 / kBlock; q++) {
+        const int i = q * kBlock + threadIdx.x;
+        const uint32_t bits = s_bmp[i];
+        if (bits && (used_bits[i] & bits) != bits) atomicOr(&used_bits[i], bits);
+      }
+    }
+  }
+}
+
+// the code points of the vocabulary and the separator (linear.cpp:92,99) join the alphabet
+__global__ __launch_bounds__(kBlock) void mark_used_kernel(const uint32_t *__restrict__ cps, size_t n,
+                                                           uint32_t *__restrict__ used_bits) {
+  size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i < n) {
+    const uint32_t cp = cps[i], b = 1u << (cp & 31u);
+    if (!(used_bits[cp >> 5] & b)) atomicOr(&used_bits[cp >> 5], b);
+  }
+  if (i == 0 && !(used_bits[0] & 2u)) atomicOr(&used_bits[0], 2u);
+}
+
+// Alphabet compaction: lut[c] = number of used code points below c (the dense symbol of a used c is lut[c] + 1).
+// One workgroup turns the bitmap into per-word prefixes (and sigma), a second launch expands them.
+constexpr int kAlphaThreads = 1024;
+constexpr int kAlphaWords = kCpWords / kAlphaThreads;  // 34 bitmap words per thread
+static_assert(kCpWords % kAlphaThreads == 0, "the bitmap divides evenly");
+__global__ __launch_bounds__(kAlphaThreads) void alphabet_prefix_kernel(const uint32_t *__restrict__ used_bits,
+                                                                       uint32_t *__restrict__ word_prefix,
+                                                                       uint32_t *__restrict__ sigma) {
+  __shared__ uint32_t s_w[kAlphaThreads / kWave];
+  const uint32_t first = threadIdx.x * kAlphaWords;
+  uint32_t bits[kAlphaWords], sum = 0;
+#pragma unroll
+  for (int i = 0; i < kAlphaWords; i++) {
+    bits[i] = used_bits[first + i];
+    sum += __popc(bits[i]);
+  }
+  const uint32_t inc = wave_incl_sum(sum);
+  if (lane_id() == kWave - 1) s_w[wave_id()] = inc;
+  __syncthreads();
+  uint32_t run = inc - sum, all = 0;
+  for (int i = 0; i < kAlphaThreads / kWave; i++) {
+    const uint32_t v = s_w[i];
+    if (i < wave_id()) run += v;
+    all += v;
+  }
+#pragma unroll
+  for (int i = 0; i < kAlphaWords; i++) {
+    word_prefix[first + i] = run;
+    run += __popc(bits[i]);
+  }
+  if (threadIdx.x == 0) *sigma = all;
+}
+__global__ __launch_bounds__(kBlock) void alphabet_lut_kernel(const uint32_t *__restrict__ used_bits,
+                                                              const uint32_t *__restrict__ word_prefix,
+                                                              uint32_t *__restrict__ lut_excl) {
+  const uint32_t cp = blockIdx.x * kBlock + threadIdx.x;  // (grid = kCpTableSize / kBlock exactly)
+  lut_excl[cp] = word_prefix[cp >> 5] + __popc(used_bits[cp >> 5] & ((1u << (cp & 31u)) - 1u));
+}
+
+// class byte of a code point (utf8.cpp:10-29 + the handle's list of "soft" spacing chars, usually empty)
+__device__ __forceinline__ uint8_t class_of_cp(uint32_t c, const uint32_t *__restrict__ soft, int nsoft) {
+  uint8_t f = 0;
+  if (is_space(c)) f |= kClsSpace;
+  if (is_punctuation(c)) f |= kClsPunct;
+  if (is_spacing_char(c)) {
+    f |= kClsSpacing;
+    int lo = 0, hi = nsoft;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (soft[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    if (lo < nsoft && soft[lo] == c) f |= kClsSoft;
+  }
+  return f;
+}
+
+// Writes 16 consecutive bytes that sit in the wave's staging row at [16 lane, 16 lane + 16) to global memory at
+// dst + 16 lane, dst of ANY alignment: the staging row is re-read shifted by the (wave-uniform) misalignment so that
+// every lane stores aligned dwords; the a = dst & 3 bytes in front of the first aligned dword and behind the last one
+// are stored as bytes (they share their dword with the neighbouring row, which belongs to another wave).
+// stage: the wave's row, kDecRowBytes bytes + 16 of slack in front (stage[-4..-1] readable); count = bytes of the
+// row that are valid (a multiple of 16, or the ragged last row of the text)
+__device__ __forceinline__ void dec_flush_row_bytes(const uint32_t *stage32, uint8_t *__restrict__ dst, uint32_t count, int lane) {
+  const uint32_t a = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst)) & 3u;
+  // aligned dword m of the row covers staged bytes [4 m - a, 4 m - a + 4)
+  uint32_t *dst32 = reinterpret_cast<uint32_t *>(dst - a);
+  const uint32_t ndw = (count + a) >> 2;  // whole dwords [1, ndw) when a != 0, [0, ndw) when a == 0; ragged bytes behind
+  const uint32_t m0 = 4u * static_cast<uint32_t>(lane);
+  uint32_t s[5];
+#pragma unroll
+  for (int q = 0; q < 5; q++) s[q] = stage32[static_cast<int>(m0) + q - 1];  // dwords m0 - 1 .. m0 + 3 of the staging row
+  uint32_t o[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) o[q] = a ? __builtin_amdgcn_alignbyte(s[q + 1], s[q], 4u - a) : s[q + 1];
+  const uint32_t first_whole = a ? 1u : 0u;
+  if (m0 >= first_whole && m0 + 4u <= ndw) {
+    *reinterpret_cast<uint4 *>(dst32 + m0) = make_uint4(o[0], o[1], o[2], o[3]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t m = m0 + q;
+      if (m >= first_whole && m < ndw) {
+        dst32[m] = o[q];
+      } else {  // a partial dword at either end of the row: byte stores of the staged bytes inside [0, count)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const int sb = static_cast<int>(4u * m + b) - static_cast<int>(a);
+          if (sb >= 0 && static_cast<uint32_t>(sb) < count) dst[sb] = static_cast<uint8_t>(o[q] >> (8 * b));
+        }
+      }
+    }
+  }
+  // the last a bytes of a full row spill into dword m = count / 4 (+ a / 4), which no lane owns
+  if (a && lane == kWave - 1 && count == static_cast<uint32_t>(kDecRowBytes)) {
+    const uint32_t last = stage32[kDecRowBytes / 4 - 1];
+    for (uint32_t b = 4u - a; b < 4u; b++) dst[kDecRowBytes - 4 + b] = static_cast<uint8_t>(last >> (8 * b));
+  }
 }
 
 // pass 2 (after the alphabet is known): dense symbols, class bytes, symbol histogram; the raw code
-// points are only kept when a debug copy is requested
+// points are only kept when a debug copy is requested (or for the fast path, which works on them).
+// Per wave and row: a row of pure ASCII (the common case even in text with the odd multi-byte character) maps input
+// byte p to output element p — symbols and classes come from a 128-entry LDS table, are staged in the wave's LDS
+// row and leave as aligned 16-byte stores whatever the alignment of the output position; any other row compacts
+// the positions of its valid leads into the wave's LDS list and is then handled one output element per lane.
 template <typename SymT>
 __global__ __launch_bounds__(kBlock) void decode_write_kernel(
     const uint8_t *__restrict__ text, size_t nbytes, const uint32_t *__restrict__ tile_prefix,
     const uint32_t *__restrict__ lut_excl, SymT *__restrict__ sym, uint8_t *__restrict__ cls,
     uint32_t *__restrict__ cps_dbg, const uint32_t *__restrict__ soft, int nsoft, uint32_t *__restrict__ sym_hist,
     int hist_shift) {
-  __shared__ uint32_t sm[8];
-  __shared__ uint32_t scp[kDecTile];
+  constexpr int WAVES = kBlock / kWave;
+  constexpr int kStageWords = kDecRowBytes / 4 + 8;  // 16 bytes of slack in front of a row, the four bytes behind it
+  __shared__ uint32_t s_stage[WAVES][2][kStageWords];  // per wave: [0] symbols (ASCII row) / raw bytes (mixed row), [1] classes
+  __shared__ uint16_t s_list[WAVES][kDecRowBytes];     // positions of the valid leads of a mixed row
+  __shared__ uint32_t s_rows[WAVES][kDecRows];
   __shared__ uint32_t shist[256];
   __shared__ uint16_t s_ascii[128];  // (class byte << 8) | dense symbol of the ASCII code points
   // The symbol histogram only steers the code lengths (any histogram gives a valid code), so it is
-  // taken from every 16th tile of large inputs: the per-tile flush is ~50 same-address atomics.
+  // taken from every 16th tile of large inputs.
   // (wide alphabets: the histogram is over symbol >> hist_shift, the coded part of the split code)
-  const bool sampled = sym_hist != nullptr && (gridDim.x < 256 || (blockIdx.x & 15) == 0);
+  const bool sampled = sym_hist != nullptr && (gridDim.x < 64 || (blockIdx.x & 15) == 0);
+  const int lane = lane_id(), wv = wave_id();
   shist[threadIdx.x] = 0;
-  auto class_of = [&](uint32_t c) {
-    uint8_t f = 0;
-    if (is_space(c)) f |= kClsSpace;
-    if (is_punctuation(c)) f |= kClsPunct;
-    if (is_spacing_char(c)) {
-      f |= kClsSpacing;
-      int lo = 0, hi = nsoft;  // sorted list of "soft" spacing chars (usually empty)
-      while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (soft[mid] < c) lo = mid + 1; else hi = mid;
-      }
-      if (lo < nsoft && soft[lo] == c) f |= kClsSoft;
-    }
-    return f;
-  };
   // (lut_excl == nullptr / sym == nullptr: no dense symbols — the fast path works on the raw code points in cps_dbg)
   if (threadIdx.x < 128) {
     const uint32_t c = threadIdx.x;
-    s_ascii[c] = static_cast<uint16_t>((static_cast<uint32_t>(class_of(c)) << 8) | (lut_excl ? ((lut_excl[c] + 1u) & 0xffu) : 0u));
+    s_ascii[c] = static_cast<uint16_t>((static_cast<uint32_t>(class_of_cp(c, soft, nsoft)) << 8) |
+                                       (lut_excl && sizeof(SymT) == 1 ? ((lut_excl[c] + 1u) & 0xffu) : 0u));
   }
-  const size_t off = static_cast<size_t>(blockIdx.x) * kDecTile + static_cast<size_t>(threadIdx.x) * kDecBytes;
-  uint32_t cp[kDecBytes];
-  uint32_t cnt = 0;
-  if (off < nbytes) {
-    uint8_t b[20];
-    load_bytes20(text, nbytes, off, b);
-    bool ascii = off + kDecBytes <= nbytes;
+  if (lane < 4) {
+    s_stage[wv][0][lane] = 0u;  // the slack in front of the rows (read by the shifted flush, never stored)
+    s_stage[wv][1][lane] = 0u;
+  }
+  const size_t tile_base = static_cast<size_t>(blockIdx.x) * kDecTile;
+  const size_t wave_base = tile_base + static_cast<size_t>(wv) * kDecWaveBytes;
+  uint32_t w[kDecRows][5];
+  dec_load_rows(text, nbytes, wave_base, lane, w);
+  // valid starts per lane and row (16-bit masks), row totals
+  uint32_t starts[kDecRows], row_cnt[kDecRows];
+  uint64_t row_ascii = 0;  // bit r: every lane's chunk of row r is pure ASCII and inside the text
 #pragma unroll
-    for (int j = 0; j < kDecBytes; j++) ascii = ascii && b[j] < 0x80;
+  for (int r = 0; r < kDecRows; r++) {
+    const size_t off = wave_base + static_cast<size_t>(r) * kDecRowBytes + static_cast<size_t>(lane) * kDecChunk;
+    const uint32_t inside = dec_inside16(off, nbytes);
+    const bool ascii = ((w[r][0] | w[r][1] | w[r][2] | w[r][3]) & kHi) == 0u;
+    uint32_t m = 0;
     if (ascii) {
-#pragma unroll
-      for (int j = 0; j < kDecBytes; j++) cp[j] = b[j];
-      cnt = kDecBytes;
+      m = inside;
     } else {
 #pragma unroll
-      for (int j = 0; j < kDecBytes; j++) {
-        cp[j] = kInvalidUnicode;
-        if (off + j < nbytes && (b[j] & 0xc0u) != 0x80u) {
-          cp[j] = decode_one(&b[j], static_cast<int64_t>(nbytes - (off + j)));
-          if (cp[j] != kInvalidUnicode) cnt++;
-        }
+      for (int k = 0; k < 4; k++) {
+        const Utf8Starts u = utf8_starts(w[r][k], w[r][k + 1]);
+        m |= byte_mask4(u.v1 | u.v2 | u.v3 | u.v4) << (4 * k);
       }
+      m &= inside;
     }
-  } else {
-#pragma unroll
-    for (int j = 0; j < kDecBytes; j++) cp[j] = kInvalidUnicode;
+    starts[r] = m;
+    if (__ballot(ascii && inside == 0xffffu) == ~0ull) row_ascii |= 1ull << r;
+    row_cnt[r] = wave_reduce_sum(__popc(m));
   }
-  uint32_t tot;
-  uint32_t pos = block_excl_sum(cnt, sm, tot);
+  if (lane == 0) {
 #pragma unroll
-  for (int j = 0; j < kDecBytes; j++) {
-    if (cp[j] != kInvalidUnicode) scp[pos++] = cp[j];
+    for (int r = 0; r < kDecRows; r++) s_rows[wv][r] = row_cnt[r];
   }
   __syncthreads();
-  const size_t out_base = tile_prefix[blockIdx.x];
-  for (uint32_t k = threadIdx.x; k < tot; k += kBlock) {
-    const uint32_t c = scp[k];
-    uint32_t sv;
-    uint8_t f;
-    if (c < 128 && sizeof(SymT) == 1) {
-      const uint32_t e = s_ascii[c];
-      sv = e & 0xffu;
-      f = static_cast<uint8_t>(e >> 8);
+  size_t out = tile_prefix[blockIdx.x];  // output position of the wave's current row
+  for (int i = 0; i < wv; i++) {
+#pragma unroll
+    for (int r = 0; r < kDecRows; r++) out += s_rows[i][r];
+  }
+  uint32_t *stage_a = &s_stage[wv][0][4], *stage_b = &s_stage[wv][1][4];  // (16 bytes of slack in front)
+#pragma unroll
+  for (int r = 0; r < kDecRows; r++) {
+    if (row_cnt[r] == 0) continue;  // (wave-uniform)
+    if ((row_ascii >> r) & 1ull) {
+      // ---- a row of pure ASCII: output element = input byte
+      uint32_t sy[4], cl[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        sy[k] = cl[k] = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t e = s_ascii[(w[r][k] >> (8 * j)) & 0x7fu];
+          sy[k] |= (e & 0xffu) << (8 * j);
+          cl[k] |= (e >> 8) << (8 * j);
+        }
+      }
+      if (sampled && sizeof(SymT) == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) atomicAdd(&shist[((sy[k] >> (8 * j)) & 0xffu) >> hist_shift], 1u);
+        }
+      }
+      const size_t e0 = out + static_cast<size_t>(lane) * kDecChunk;
+      if (sizeof(SymT) == 1 && sym) {
+        reinterpret_cast<uint4 *>(stage_a)[lane] = make_uint4(sy[0], sy[1], sy[2], sy[3]);
+      }
+      reinterpret_cast<uint4 *>(stage_b)[lane] = make_uint4(cl[0], cl[1], cl[2], cl[3]);
+      __builtin_amdgcn_wave_barrier();
+      if (sizeof(SymT) == 1 && sym) dec_flush_row_bytes(stage_a, reinterpret_cast<uint8_t *>(sym) + out, kDecRowBytes, lane);
+      dec_flush_row_bytes(stage_b, cls + out, kDecRowBytes, lane);
+      __builtin_amdgcn_wave_barrier();
+      if (sizeof(SymT) == 4 && sym) {  // 4-byte symbols: 16 consecutive elements per lane, always dword aligned
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          uint32_t v[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint32_t c = (w[r][k] >> (8 * j)) & 0x7fu;
+            v[j] = lut_excl[c] + 1u;
+            if (sampled) atomicAdd(&shist[(v[j] >> hist_shift) & 255u], 1u);
+          }
+          *reinterpret_cast<uint4 *>(reinterpret_cast<uint32_t *>(sym) + e0 + 4 * k) = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      if (cps_dbg) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          *reinterpret_cast<uint4 *>(cps_dbg + e0 + 4 * k) =
+              make_uint4(w[r][k] & 0xffu, (w[r][k] >> 8) & 0xffu, (w[r][k] >> 16) & 0xffu, w[r][k] >> 24);
+        }
+      }
     } else {
-      sv = lut_excl ? lut_excl[c] + 1u : 0u;
-      f = class_of(c);
+      // ---- a mixed row: positions of the valid leads -> the wave's list, raw bytes -> the wave's staging row
+      const uint32_t c = __popc(starts[r]);
+      uint32_t o = wave_incl_sum(c) - c;
+      reinterpret_cast<uint4 *>(stage_a)[lane] = make_uint4(w[r][0], w[r][1], w[r][2], w[r][3]);
+      if (lane == kWave - 1) stage_a[kDecRowBytes / 4] = w[r][4];  // the four bytes behind the row
+      uint32_t m = starts[r];
+      while (m) {
+        const int j = __ffs(static_cast<int>(m)) - 1;
+        m &= m - 1u;
+        s_list[wv][o++] = static_cast<uint16_t>(lane * kDecChunk + j);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t e = lane; e < row_cnt[r]; e += kWave) {
+        const uint32_t pos = s_list[wv][e];
+        const uint32_t x = __builtin_amdgcn_alignbyte(stage_a[(pos >> 2) + 1], stage_a[pos >> 2], pos & 3u);
+        const uint32_t cp = utf8_value(x);
+        uint32_t sv;
+        uint8_t f;
+        if (cp < 128u && sizeof(SymT) == 1) {
+          const uint32_t en = s_ascii[cp];
+          sv = en & 0xffu;
+          f = static_cast<uint8_t>(en >> 8);
+        } else {
+          sv = lut_excl ? lut_excl[cp] + 1u : 0u;
+          f = cp < 128u ? static_cast<uint8_t>(s_ascii[cp] >> 8) : class_of_cp(cp, soft, nsoft);
+        }
+        if (sym) sym[out + e] = static_cast<SymT>(sv);
+        if (sampled) atomicAdd(&shist[(sv >> hist_shift) & 255u], 1u);
+        if (cps_dbg) cps_dbg[out + e] = cp;
+        cls[out + e] = f;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    if (sym) sym[out_base + k] = static_cast<SymT>(sv);
-    if (sampled) atomicAdd(&shist[(sv >> hist_shift) & 255u], 1u);
-    if (cps_dbg) cps_dbg[out_base + k] = c;
-    cls[out_base + k] = f;
+    out += row_cnt[r];
   }
   if (sampled) {
     __syncthreads();
     if (shist[threadIdx.x]) atomicAdd(&sym_hist[threadIdx.x], shist[threadIdx.x]);
   }
-}
-
-__global__ __launch_bounds__(kBlock) void mark_used_kernel(const uint32_t *__restrict__ cps, size_t n,
-                                                           uint32_t *__restrict__ used) {
-  size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i < n) used[cps[i]] = 1u;
-  if (i == 0) used[1] = 1u;  // the separator (linear.cpp:92,99)
 }
 
 // the separator and the vocab stream behind the text: sym[n_text + k] (dense, order-preserving

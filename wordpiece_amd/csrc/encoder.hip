@@ -149,7 +149,7 @@ struct Context {
   uint32_t *d_trie_child = nullptr;
   int32_t *d_trie_id = nullptr;
   DeviceBuffer text_buf, a_buf, b_buf, fmt_buf;  // fmt_buf: id text of encodeExternal
-  uint32_t *d_used = nullptr, *d_lut = nullptr, *d_scan_tmp = nullptr;  // code point tables
+  uint32_t *d_used = nullptr, *d_lut = nullptr, *d_scan_tmp = nullptr;  // bitmap of the code points in use (kCpWords), lut (kCpTableSize), per-word prefixes (kCpWords)
   uint32_t *d_scalars = nullptr;                                         // kScalars words of device scalars
   uint8_t *d_code = nullptr;     // symbol code tables: cw u16[256] | len u8[256] | bmask u16[4096]
   // The symbol code of the last encode, kept while the alphabet size stays the same: ANY order-preserving code over
@@ -369,9 +369,9 @@ static std::unique_ptr<Context> make_context(const wp_vocab *v, int device) {
   WP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   WP_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   for (auto &e : c->evs) WP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  WP_HIP(hipMalloc(&c->d_used, sizeof(uint32_t) * kCpTableSize));
+  WP_HIP(hipMalloc(&c->d_used, sizeof(uint32_t) * kCpWords));
   WP_HIP(hipMalloc(&c->d_lut, sizeof(uint32_t) * kCpTableSize));
-  WP_HIP(hipMalloc(&c->d_scan_tmp, sizeof(uint32_t) * (cdiv(kCpTableSize, kScanTile) + 8)));
+  WP_HIP(hipMalloc(&c->d_scan_tmp, sizeof(uint32_t) * kCpWords));
   WP_HIP(hipMalloc(&c->d_scalars, sizeof(uint32_t) * kScalars));
   WP_HIP(hipMalloc(&c->d_code, 512 + 256 + kDecodeTableBytes));
   WP_HIP(hipHostMalloc(&c->h_code, 512 + 256 + kDecodeTableBytes));
@@ -444,16 +444,19 @@ static void encode_on_device(const wp_vocab *v, Context *c, const uint8_t *d_tex
   }
   aa.arm(st);
   WP_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(uint32_t) * kScalars, st));
-  WP_HIP(hipMemsetAsync(c->d_used, 0, sizeof(uint32_t) * kCpTableSize, st));
-  hipLaunchKernelGGL(decode_count_kernel, dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes, d_tile_cnt,
+  WP_HIP(hipMemsetAsync(c->d_used, 0, sizeof(uint32_t) * kCpWords, st));
+  hipLaunchKernelGGL(decode_count_kernel<true>, dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes, d_tile_cnt,
                      reinterpret_cast<unsigned long long *>(c->d_scalars + 2), c->d_used);
   device_exclusive_scan(d_tile_cnt, d_tile_cnt, dec_tiles, d_cnt_tmp, c->d_scalars + 0, st, nullptr,
                         reinterpret_cast<unsigned long long *>(c->d_scalars + 14));
   // does the text itself hold code point 0 or 1 (the separator)?  (read before the vocab marks its symbols)
-  WP_HIP(hipMemcpyAsync(c->d_scalars + 20, c->d_used, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  // (bits 0 and 1 of the first bitmap word)
+  WP_HIP(hipMemcpyAsync(c->d_scalars + 20, c->d_used, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(mark_used_kernel, dim3(cdiv(std::max<size_t>(hv.stream.size(), 1), kBlock)), dim3(kBlock), 0,
                      st, c->d_stream, hv.stream.size(), c->d_used);
-  device_exclusive_scan(c->d_used, c->d_lut, kCpTableSize, c->d_scan_tmp, c->d_scalars + 1, st);
+  // alphabet: bitmap -> per-word prefixes + sigma -> lut (dense symbol of a used code point c = lut[c] + 1)
+  hipLaunchKernelGGL(alphabet_prefix_kernel, dim3(1), dim3(kAlphaThreads), 0, st, c->d_used, c->d_scan_tmp, c->d_scalars + 1);
+  hipLaunchKernelGGL(alphabet_lut_kernel, dim3(kCpTableSize / kBlock), dim3(kBlock), 0, st, c->d_used, c->d_scan_tmp, c->d_lut);
   WP_LAUNCH_CHECK();
   fetch_scalars(c, 22);
   unsigned long long n_text64;
@@ -467,8 +470,8 @@ static void encode_on_device(const wp_vocab *v, Context *c, const uint8_t *d_tex
   // (they sort around the separator), and on request (WP_OPT_VOCAB_IN_S).
   static const bool env_vocab_in_s = env_flag("WP_VOCAB_IN_S");
   const bool full_sa = v->full_depth || hv.n_dup_eligible > 0 || v->lcp_kasai;
-  const bool text_only = !full_sa && !v->vocab_in_s && !env_vocab_in_s && !hv.low_cp && c->h_scalars[20] == 0 &&
-                         c->h_scalars[21] == 0 && !env_flag("WP_NO_PRUNE");
+  const bool text_only = !full_sa && !v->vocab_in_s && !env_vocab_in_s && !hv.low_cp && (c->h_scalars[20] & 3u) == 0 &&
+                         !env_flag("WP_NO_PRUNE");
   S.vocab_in_s = text_only ? 0 : 1;
   const uint32_t sigma = c->h_scalars[1];
   unsigned long long dropped;
@@ -1322,9 +1325,8 @@ static void encode_fast_on_device(const wp_vocab *v, Context *c, const uint8_t *
   }
   aa.arm(st);
   WP_HIP(hipMemsetAsync(c->d_scalars, 0, sizeof(uint32_t) * kScalars, st));
-  // (decode_count also marks used code points: not needed here, but the table is the handle's anyway)
-  hipLaunchKernelGGL(decode_count_kernel, dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes, d_tile_cnt,
-                     reinterpret_cast<unsigned long long *>(c->d_scalars + 2), c->d_used);
+  hipLaunchKernelGGL(decode_count_kernel<false>, dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes, d_tile_cnt,
+                     reinterpret_cast<unsigned long long *>(c->d_scalars + 2), static_cast<uint32_t *>(nullptr));
   device_exclusive_scan(d_tile_cnt, d_tile_cnt, dec_tiles, d_cnt_tmp, c->d_scalars + 0, st, nullptr,
                         reinterpret_cast<unsigned long long *>(c->d_scalars + 14));
   WP_LAUNCH_CHECK();
