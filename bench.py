@@ -283,7 +283,7 @@ def main():
         step()
     fence()
     stage_ms = {}
-    radix_ms = radix_elems = radix_launches = digit_bytes = 0
+    radix_ms = radix_elems = radix_launches = digit_bytes = radix_bytes = 0
     t0 = time.perf_counter()
     n_ids = 0
     for _ in range(args.steps):
@@ -293,6 +293,7 @@ def main():
         radix_elems += st["radix_pass_elems"]
         radix_launches += st["radix_passes"]
         digit_bytes += st["radix_digit_bytes"]
+        radix_bytes += st["radix_pass_bytes"]
         for k in ("ms_total", "ms_decode", "ms_sa", "ms_lcp", "ms_scan", "ms_walk"):
             stage_ms[k] = stage_ms.get(k, 0.0) + st[k]
     fence()
@@ -318,14 +319,16 @@ def main():
             "uint32, 16" if key_bytes == 4 else "uint64, 24", (st["key_bits"] + 7) // 8, st["key_bits"],
             (" and the second destination-partition pass of the round-0 rank store (the first one also computes the ranks: "
              "the RankVals instantiation, another kernel, not counted here)" if st["rank_in_pass"] else
-             " and the destination-partition passes of the round-0 rank store") if key_bytes == 4 else "", key_bytes + 4)
+             " and the destination-partition passes of the round-0 rank store (the first one makes its value column — the slots — up)")
+            if key_bytes == 4 else "", key_bytes + 4)
         ms_per_step = dt_max / args.steps * 1e3
         value = total_bytes / 1e6 / (dt_max / args.steps)
-        # dominant kernel: the radix scatter pass.  Algorithmic bytes per launch = the (key, index) record read and
-        # written per element moved (16 B with 32-bit keys), - 4 B per symbol for the first pass, which makes the index
-        # column up instead of reading it, + 1 B per element for the digit byte it leaves for the next pass's histogram
+        # dominant kernel: the radix scatter pass.  Algorithmic bytes per launch (counted by the library per launch,
+        # wp_stats.radix_pass_bytes) = the (key, index) record read and written per element moved (16 B with 32-bit
+        # keys), - 4 B per element where the pass makes the index column up instead of reading it (the first pass of the
+        # suffix sort and of the rank store), + 1 B per element for the digit byte it leaves for the next pass's histogram
         avg_launch_ms = radix_ms / max(radix_launches, 1)
-        avg_launch_bytes = (RADIX_BYTES_PER_ELEM * radix_elems - 4 * st["n_total"] * args.steps + digit_bytes) / max(radix_launches, 1)
+        avg_launch_bytes = radix_bytes / max(radix_launches, 1)
         achieved = avg_launch_bytes / 1e9 / (avg_launch_ms / 1e3) if avg_launch_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "radix_scatter_traffic.json")
@@ -348,6 +351,7 @@ def main():
                        "symbols_per_key": st["symbols_per_key"], "key_bits": st["key_bits"], "active_per_round": st["active_per_round"],
                        "needed_after_round0": st["needed_after_round0"],
                        "radix_launches_per_step": radix_launches // steps, "staged_emit": st["staged_emit"], "rank_in_pass": st["rank_in_pass"],
+                       "trie_refine": st["trie_refine"],
                        "id_gather": ("%s: exact-size receives on rank 0" % ("rccl" if backend == "nccl" else backend)) if distributed
                        else "none (single GPU)"},
             "roofline": {"bound": "hbm", "kernel": scatter_name, "achieved": round(achieved, 1),
@@ -360,11 +364,17 @@ def main():
         # the whole SA/LCP stage against the HBM peak, SURVEY 8(d) style: algorithmic bytes only (no histogram
         # re-read of the keys: the histograms read the digit bytes)
         n_sym, act = st["n_total"], st["active_per_round"]
-        passes = radix_elems / steps + (n_sym if st["rank_in_pass"] else 0)  # (+ the partition pass that computes the ranks)
-        dig = (2 * (digit_bytes / steps + (n_sym if st["rank_in_pass"] else 0)) + n_sym) if digit_bytes else key_bytes * passes  # written + read (+ the key builder's bytes), or the key re-read
-        # (rank_in_pass: no rank kernel at all — the first partition pass reads the sorted keys in place of the ranks)
-        split = 0 if st["rank_in_pass"] else SPLIT_BYTES - (4 if st["vocab_in_s"] == 0 else 0)
-        sa_bytes = RADIX_BYTES_PER_ELEM * passes - 4 * n_sym + dig + (split + RANK_STORE_BYTES) * n_sym + ROUND_BYTES * sum(act[1:])
+        # counted scatter launches (records + the digit bytes they write), + the partition pass that computes the ranks
+        # (RankVals: sorted key 4 + position 4 read, pair 8 + digit byte written), + the digit bytes the histograms read
+        # (every byte written once is read once; the first pass's bytes come from the key builder: written + read),
+        # or the keys the histograms re-read where there are no digit bytes
+        pass_bytes = radix_bytes / steps + (17 * n_sym if st["rank_in_pass"] else 0)
+        dig_read = (digit_bytes / steps + (n_sym if st["rank_in_pass"] else 0) + 2 * n_sym) if digit_bytes else key_bytes * radix_elems / steps
+        # no rank kernel of its own where the first partition pass computes the ranks (rank_in_pass) or where a suffix's
+        # slot is its rank (trie_refine: nothing asks for group heads)
+        split = 0 if (st["rank_in_pass"] or st["trie_refine"]) else SPLIT_BYTES - (4 if st["vocab_in_s"] == 0 else 0)
+        sa_bytes = pass_bytes + dig_read + (split + RANK_STORE_BYTES) * n_sym + ROUND_BYTES * sum(act[1:])
+        dig = dig_read + (digit_bytes / steps if digit_bytes else 0)
         sa_ms = stage_ms.get("ms_sa", 0.0) / steps
         if sa_ms > 0:
             out["sa_lcp_stage"] = {"algorithmic_bytes": int(sa_bytes), "ms": round(sa_ms, 3),

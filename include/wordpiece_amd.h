@@ -79,6 +79,14 @@ int wp_linear_encode_device(wp_vocab *v, const void *d_utf8, size_t nbytes,
 int wp_linear_encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const int *devices,
                            int n_devices, int32_t **ids, size_t *n_ids);
 
+/* A sequence of texts (shards / batches of one corpus) through one handle, pipelined: the upload of text i + 1 and
+ * the download of the ids of text i - 1 run on copy streams beside the kernels of text i (second text buffer, id
+ * staging buffers), so that host to host costs what the device path costs.  Same ids per text as n_texts calls of
+ * wp_linear_encode — the reference's precedent for feeding a corpus piecewise is encodeExternal's batch loop,
+ * linear.cpp:355-371.  ids[i] (free each with wp_free; NULL for a text without ids) and n_ids[i] per text. */
+int wp_linear_encode_batch(wp_vocab *v, const char *const *texts, const size_t *nbytes, size_t n_texts,
+                           int32_t **ids, size_t *n_ids);
+
 /* Sizes the handle's device arenas and host staging for inputs of up to `nbytes`, so that the
  * first encode does not pay for the allocations (about 100 bytes of HBM per input symbol). */
 int wp_reserve(wp_vocab *v, size_t nbytes);
@@ -194,7 +202,10 @@ typedef struct {
   int32_t staged_emit;        /* 1: ids left the walk as per-workgroup lists (see WP_OPT_SPARSE_EMIT) */
   int32_t rank_in_pass;       /* 1: the ranks of round 0 were computed inside the first partition pass of the rank
                                  store (one more full-size launch of the radix scatter, not in radix_passes) */
-  int32_t reserved1;
+  int32_t trie_refine;        /* 1: the needed groups of round 0 were resolved along the token trie (one walk + one segmented
+                                 sort) instead of by prefix-doubling rounds (default in the text-only layout) */
+  int64_t radix_pass_bytes;   /* algorithmic bytes of the counted radix scatter launches: record read (without the index
+                                 column where the pass makes it up) + record written + digit byte written */
 } wp_stats;
 int wp_get_stats(const wp_vocab *v, wp_stats *out);
 

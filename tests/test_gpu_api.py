@@ -382,7 +382,7 @@ print("SWITCH_OK")
 ''' % (os.path.dirname(PKG), os.path.dirname(os.path.abspath(__file__))))
     combos = [{"WP_NO_RANK_FUSION": "1", "WP_NO_STEP_PACK": "1"}, {"WP_RANK_STORE_SCATTER": "1", "WP_HIST_SKEW": "0"},
               {"WP_GLOBAL_NEED": "1", "WP_NO_CODE_CACHE": "1", "WP_SPARSE_EMIT": "1"},
-              {"WP_NO_PRUNE": "1"}, {"WP_VOCAB_IN_S": "1", "WP_NO_DIGIT_BYTES": "1"}]
+              {"WP_NO_PRUNE": "1"}, {"WP_VOCAB_IN_S": "1", "WP_NO_DIGIT_BYTES": "1"}, {"WP_DOUBLING_ROUNDS": "1"}]
     for combo in combos:
         env = dict(os.environ, **combo)
         r = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)

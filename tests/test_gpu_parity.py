@@ -172,9 +172,17 @@ def test_fused_rerank_deep_prefix_8mb_ids():
     text, vocab = synth.deep_prefix_corpus(8_000_000, seed=14)
     gv = W.Vocab(vocab)
     gv.set_option(W.WP_OPT_FUSED_RERANK, 1)
+    gv.set_option(W.WP_OPT_VOCAB_IN_S, 1)  # (the doubling rounds: the default layout resolves its needed groups along the token trie)
     ids = gv.encode(text)
     assert gv.stats()["rounds"] >= 4
-    assert np.array_equal(ids, _oracle_ids_fast(text, vocab))
+    exp = _oracle_ids_fast(text, vocab)
+    assert np.array_equal(ids, exp)
+    # default layout: one trie walk + one segmented sort whatever the depth of the vocabulary
+    gv = W.Vocab(vocab)
+    gv.set_option(W.WP_OPT_FUSED_RERANK, 1)
+    assert np.array_equal(gv.encode(text), exp)
+    st = gv.stats()
+    assert st["trie_refine"] == 1 and st["rounds"] == 2 and st["vocab_in_s"] == 0
 
 
 def _cover_ids(text, vocab):
@@ -420,9 +428,18 @@ def test_deep_prefix_24mb_ids():
     gv = W.Vocab(vocab)
     ids = gv.encode(text)
     st = gv.stats()
-    # (the groups that carry a long token's key are refined until their depth exceeds the longest token)
-    assert st["longest_token"] == 512 and st["rounds"] >= 7 and 0 < st["needed_after_round0"] < st["n_total"] // 50
-    assert np.array_equal(ids, _oracle_ids_fast(text, vocab))
+    # (the groups that carry a long token's key are resolved along the token trie: one walk + one segmented sort,
+    # however deep the vocabulary — the doubling rounds took 80 + rounds here)
+    assert st["longest_token"] == 512 and st["rounds"] == 2 and st["trie_refine"] == 1
+    assert 0 < st["needed_after_round0"] < st["n_total"] // 50
+    exp = _oracle_ids_fast(text, vocab)
+    assert np.array_equal(ids, exp)
+    # the same text through the reference's layout: prefix doubling until the depth exceeds the longest token
+    gv = W.Vocab(vocab)
+    gv.set_option(W.WP_OPT_VOCAB_IN_S, 1)
+    assert np.array_equal(gv.encode(text), exp)
+    st = gv.stats()
+    assert st["trie_refine"] == 0 and st["rounds"] >= 7
 
 
 def _ids_both_layouts(text, vocab, label=""):
@@ -453,7 +470,7 @@ def test_vocab_structure_layout_equals_reference_layout():
     assert sa["vocab_in_s"] == 0 and sa["alphabet"] > 255
     text, vocab = synth.deep_prefix_corpus(3_000_000, seed=53)
     sa, sb = _ids_both_layouts(text, vocab, "deep")
-    assert sa["vocab_in_s"] == 0 and sa["rounds"] >= 5 and sb["n_total"] - sa["n_total"] > 10_000_000
+    assert sa["vocab_in_s"] == 0 and sa["rounds"] == 2 and sb["rounds"] >= 5 and sb["n_total"] - sa["n_total"] > 10_000_000
     for case in _load("reference_tests_cpp.json") + _load("survey_probed_cases.json"):
         t = bytes.fromhex(case["text_hex"])
         vc = [bytes.fromhex(w) for w in case["vocab_hex"]]

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "wp_linear_encode_device", "wp_linear_encode_file", "wp_linear_encode_external", "wp_set_option",
     "wp_get_stats", "wp_linear_debug_fetch", "wp_free", "wp_last_error", "wp_device_count",
     "wp_linear_encode_multi", "wp_reserve", "wp_fast_encode", "wp_fast_encode_device", "wp_fast_encode_file",
-    "wp_fast_encode_external", "wp_vocab_token_utf8", "wp_trim",
+    "wp_fast_encode_external", "wp_vocab_token_utf8", "wp_trim", "wp_linear_encode_batch",
 ]
 
 
@@ -52,7 +52,7 @@ class Stats(C.Structure):
                 ("radix_digit_bytes", C.c_int64), ("ms_host_total", C.c_double), ("guard_zones", C.c_int32),
                 ("n_devices", C.c_int32), ("vocab_in_s", C.c_int32), ("reserved0", C.c_int32),
                 ("needed_after_round0", C.c_int64), ("key_bits", C.c_int32), ("staged_emit", C.c_int32),
-                ("rank_in_pass", C.c_int32), ("reserved1", C.c_int32)]
+                ("rank_in_pass", C.c_int32), ("trie_refine", C.c_int32), ("radix_pass_bytes", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "active_per_round"}
@@ -89,6 +89,8 @@ def lib():
         L.wp_linear_encode_multi.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.POINTER(i32p),
                                              C.POINTER(C.c_size_t)]
         L.wp_reserve.argtypes = [vp, C.c_size_t]
+        L.wp_linear_encode_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(i32p),
+                                             C.POINTER(C.c_size_t)]
         L.wp_trim.argtypes = [vp]
         L.wp_fast_encode.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32p), C.POINTER(C.c_size_t)]
         L.wp_fast_encode_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -206,6 +208,18 @@ class Vocab:
             rc = lib().wp_linear_encode_multi(self._h, b, len(b), None, int(devices or 0), C.byref(ids), C.byref(n))
         _check(rc)
         return _adopt_ids(ids, n.value)
+
+    def encode_batch(self, texts):
+        """A sequence of host texts through the shard pipeline (wp_linear_encode_batch): uploads, kernels and id
+        downloads of neighbouring texts overlap.  Returns one numpy int32 array per text."""
+        bs = [_bytes(t) for t in texts]
+        k = len(bs)
+        ptrs = (C.c_char_p * k)(*bs)
+        sizes = (C.c_size_t * k)(*[len(b) for b in bs])
+        ids = (C.POINTER(C.c_int32) * k)()
+        ns = (C.c_size_t * k)()
+        _check(lib().wp_linear_encode_batch(self._h, ptrs, sizes, k, ids, ns))
+        return [_adopt_ids(C.cast(ids[i], C.POINTER(C.c_int32)), ns[i]) for i in range(k)]
 
     def reserve(self, nbytes):
         """Pre-sizes the device arenas and host staging for inputs of up to nbytes (wp_reserve)."""

@@ -8,6 +8,7 @@
 #pragma once
 #include "code.h"
 #include "primitives.h"
+#include "utf8_swar.h"
 
 namespace wp {
 
@@ -25,54 +26,8 @@ constexpr int kDecWaveBytes = kDecRowBytes * kDecRows;      // 4 KB
 constexpr int kDecTile = (kBlock / kWave) * kDecWaveBytes;  // 16 KB of input per workgroup
 constexpr uint32_t kCpTableSize = 0x110000;                 // lut[] covers every code point
 constexpr uint32_t kCpWords = kCpTableSize / 32;            // the used-code-point bitmap
-constexpr uint32_t kHi = 0x80808080u;
 
-// per byte position of a word (bit 7 of byte j): does a valid 1 / 2 / 3 / 4-byte sequence start here?
-// Same verdicts as decode_one (utf8.cpp:54-90): w0 = the word, nx = the four bytes behind it.
-struct Utf8Starts {
-  uint32_t v1, v2, v3, v4;
-};
-__device__ __forceinline__ Utf8Starts utf8_starts(uint32_t w0, uint32_t nx) {
-  const uint32_t w1 = __builtin_amdgcn_alignbyte(nx, w0, 1);  // byte j of w1 = the byte behind byte j of w0
-  const uint32_t w2 = __builtin_amdgcn_alignbyte(nx, w0, 2);
-  const uint32_t w3 = __builtin_amdgcn_alignbyte(nx, w0, 3);
-  auto cont = [](uint32_t x) { return x & ~(x << 1) & kHi; };  // 10xxxxxx
-  const uint32_t c1 = cont(w1), c2 = cont(w2), c3 = cont(w3);
-  const uint32_t s1 = w0 << 1, s2 = w0 << 2, s3 = w0 << 3, s4 = w0 << 4;  // bit 7 of a byte <- its bit 6 / 5 / 4 / 3
-  const uint32_t l2 = w0 & s1 & ~s2 & kHi;                                  // 110xxxxx
-  const uint32_t l3 = w0 & s1 & s2 & ~s3 & kHi;                             // 1110xxxx
-  const uint32_t l4 = w0 & s1 & s2 & s3 & ~s4 & kHi;                        // 11110xxx
-  auto byte_zero = [](uint32_t x) { return ~(x + 0x7f7f7f7fu) & kHi; };     // (bytes of x <= 0x7f: no carries)
-  const uint32_t over2 = byte_zero(w0 & 0x1e1e1e1eu);                       // C0, C1: code point < 0x80
-  const uint32_t lo4 = w0 & 0x0f0f0f0fu;
-  const uint32_t n5 = w1 << 2;                                              // bit 5 of the next byte
-  // E0 80..9F: code point < 0x800; ED A0..BF: surrogates
-  const uint32_t bad3 = (byte_zero(lo4) & ~n5) | (byte_zero(lo4 ^ 0x0d0d0d0du) & n5);
-  const uint32_t lo3 = w0 & 0x07070707u;
-  const uint32_t n54 = (w1 << 2) | (w1 << 3);                               // next byte >= 0x90 (a continuation byte)
-  // F0 80..8F: code point < 0x10000; F4 90..: > U+10FFFF; F5..F7
-  const uint32_t bad4 = (byte_zero(lo3) & ~n54) | (byte_zero(lo3 ^ 0x04040404u) & n54) | ((w0 << 5) & ((w0 << 6) | (w0 << 7)));
-  Utf8Starts r;
-  r.v1 = ~w0 & kHi;
-  r.v2 = l2 & c1 & ~over2;
-  r.v3 = l3 & c1 & c2 & ~bad3 & kHi;
-  r.v4 = l4 & c1 & c2 & c3 & ~bad4 & kHi;
-  return r;
-}
-// the code point of a VALID sequence: x = the four bytes from its lead on
-__device__ __forceinline__ uint32_t utf8_value(uint32_t x) {
-  const uint32_t b0 = x & 0xffu, b1 = (x >> 8) & 0x3fu, b2 = (x >> 16) & 0x3fu, b3 = (x >> 24) & 0x3fu;
-  if (b0 < 0x80u) return b0;
-  if (b0 < 0xe0u) return ((b0 & 0x1fu) << 6) | b1;
-  if (b0 < 0xf0u) return ((b0 & 0x0fu) << 12) | (b1 << 6) | b2;
-  return ((b0 & 0x07u) << 18) | (b1 << 12) | (b2 << 6) | b3;
-}
-// bit 7 of byte j -> bit j
-__device__ __forceinline__ uint32_t byte_mask4(uint32_t m) {
-  const uint32_t x = m >> 7;
-  return (x | (x >> 7) | (x >> 14) | (x >> 21)) & 0xfu;
-}
-
+typedef uint32_t dec_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 // The rows of a wave: w[r][0..3] = the lane's 16 bytes of row r, w[r][4] = the four bytes behind them.  Bytes at or
 // behind nbytes read as zero (never a continuation byte: a sequence cut off by the end of the text is invalid, as
 // decode_one's size test has it).  text: 4-byte aligned, readable up to the next multiple of 16 behind nbytes.
@@ -82,12 +37,12 @@ __device__ __forceinline__ void dec_load_rows(const uint8_t *__restrict__ text, 
 #pragma unroll
   for (int r = 0; r < kDecRows; r++) {
     const size_t off = wave_base + static_cast<size_t>(r) * kDecRowBytes + static_cast<size_t>(lane) * kDecChunk;
-    if (off < padded) {
-      const uint32_t *p = reinterpret_cast<const uint32_t *>(text + off);
-      w[r][0] = p[0];
-      w[r][1] = p[1];
-      w[r][2] = p[2];
-      w[r][3] = p[3];
+    if (off < padded) {  // (one 16-byte load: global memory wants dword alignment for it, which the text has)
+      const dec_u32x4 v = *reinterpret_cast<const dec_u32x4 *>(text + off);
+      w[r][0] = v.x;
+      w[r][1] = v.y;
+      w[r][2] = v.z;
+      w[r][3] = v.w;
     } else {
       w[r][0] = w[r][1] = w[r][2] = w[r][3] = 0u;
     }
@@ -244,15 +199,13 @@ __global__ __launch_bounds__(kBlock) void decode_count_kernel(const uint8_t *__r
   }
 }
 
-// the code points of the vocabulary and the separator (linear.cpp:92,99) join the alphabet
-__global__ __launch_bounds__(kBlock) void mark_used_kernel(const uint32_t *__restrict__ cps, size_t n,
-                                                           uint32_t *__restrict__ used_bits) {
-  size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (i < n) {
-    const uint32_t cp = cps[i], b = 1u << (cp & 31u);
-    if (!(used_bits[cp >> 5] & b)) atomicOr(&used_bits[cp >> 5], b);
-  }
-  if (i == 0 && !(used_bits[0] & 2u)) atomicOr(&used_bits[0], 2u);
+// the code points of the vocabulary and the separator (linear.cpp:92,99) join the alphabet: the vocabulary's words
+// of the bitmap come precomputed from the host (vocab.h: one entry per bitmap word, so no two threads meet)
+__global__ __launch_bounds__(kBlock) void vocab_alphabet_kernel(const uint32_t *__restrict__ word_idx,
+                                                                const uint32_t *__restrict__ word_bits, uint32_t n,
+                                                                uint32_t *__restrict__ used_bits) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) used_bits[word_idx[i]] |= word_bits[i];
 }
 
 // Alphabet compaction: lut[c] = number of used code points below c (the dense symbol of a used c is lut[c] + 1).
@@ -294,8 +247,11 @@ __global__ __launch_bounds__(kBlock) void alphabet_lut_kernel(const uint32_t *__
   lut_excl[cp] = word_prefix[cp >> 5] + __popc(used_bits[cp >> 5] & ((1u << (cp & 31u)) - 1u));
 }
 
-// class byte of a code point (utf8.cpp:10-29 + the handle's list of "soft" spacing chars, usually empty)
-__device__ __forceinline__ uint8_t class_of_cp(uint32_t c, const uint32_t *__restrict__ soft, int nsoft) {
+// class byte of a code point (utf8.cpp:10-29 + the handle's list of "soft" spacing chars, usually empty): the BMP
+// through the handle's table (vocab.h, cls_bmp), the rest computed
+__device__ __forceinline__ uint8_t class_of_cp(uint32_t c, const uint8_t *__restrict__ cls_bmp, const uint32_t *__restrict__ soft,
+                                               int nsoft) {
+  if (c < 0x10000u) return cls_bmp[c];
   uint8_t f = 0;
   if (is_space(c)) f |= kClsSpace;
   if (is_punctuation(c)) f |= kClsPunct;
@@ -364,8 +320,8 @@ template <typename SymT>
 __global__ __launch_bounds__(kBlock) void decode_write_kernel(
     const uint8_t *__restrict__ text, size_t nbytes, const uint32_t *__restrict__ tile_prefix,
     const uint32_t *__restrict__ lut_excl, SymT *__restrict__ sym, uint8_t *__restrict__ cls,
-    uint32_t *__restrict__ cps_dbg, const uint32_t *__restrict__ soft, int nsoft, uint32_t *__restrict__ sym_hist,
-    int hist_shift) {
+    uint32_t *__restrict__ cps_dbg, const uint8_t *__restrict__ cls_bmp, const uint32_t *__restrict__ soft, int nsoft,
+    uint32_t *__restrict__ sym_hist, int hist_shift) {
   constexpr int WAVES = kBlock / kWave;
   constexpr int kStageWords = kDecRowBytes / 4 + 8;  // 16 bytes of slack in front of a row, the four bytes behind it
   __shared__ uint32_t s_stage[WAVES][2][kStageWords];  // per wave: [0] symbols (ASCII row) / raw bytes (mixed row), [1] classes
@@ -382,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void decode_write_kernel(
   // (lut_excl == nullptr / sym == nullptr: no dense symbols — the fast path works on the raw code points in cps_dbg)
   if (threadIdx.x < 128) {
     const uint32_t c = threadIdx.x;
-    s_ascii[c] = static_cast<uint16_t>((static_cast<uint32_t>(class_of_cp(c, soft, nsoft)) << 8) |
+    s_ascii[c] = static_cast<uint16_t>((static_cast<uint32_t>(cls_bmp[c]) << 8) |
                                        (lut_excl && sizeof(SymT) == 1 ? ((lut_excl[c] + 1u) & 0xffu) : 0u));
   }
   if (lane < 4) {
@@ -504,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void decode_write_kernel(
           f = static_cast<uint8_t>(en >> 8);
         } else {
           sv = lut_excl ? lut_excl[cp] + 1u : 0u;
-          f = cp < 128u ? static_cast<uint8_t>(s_ascii[cp] >> 8) : class_of_cp(cp, soft, nsoft);
+          f = cp < 128u ? static_cast<uint8_t>(s_ascii[cp] >> 8) : class_of_cp(cp, cls_bmp, soft, nsoft);
         }
         if (sym) sym[out + e] = static_cast<SymT>(sv);
         if (sampled) atomicAdd(&shist[(sv >> hist_shift) & 255u], 1u);
@@ -675,6 +631,102 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
       const Key0 k = skey[key_pad(li)];
       keys[i] = k;  // (the values, 0..n-1, are made up by the first radix pass)
       if (dig0) dig0[i] = static_cast<uint8_t>(k);  // first radix digit: that pass's histogram reads 1 byte per key
+    }
+  }
+}
+
+// The same keys for 8-bit symbols, out of registers: a lane owns 16 consecutive positions (one 16-byte load) and
+// reads the 16 behind them (a second load that mostly hits L1), builds the key of its LAST position from the
+// codewords of the following symbols and rolls the other 15 out of it, all with compile-time byte positions, and
+// stores 16 keys (64 contiguous bytes) and their 16 first digits (one 16-byte store) straight from registers:
+// no staging of symbols or keys in LDS, no barrier behind the table load.  The 17 symbols from the last position
+// on must hold kKeyBits bits: the host takes this kernel only when every codeword has at least
+// kKeys8MinLen bits (17 x 2 >= 32; a code with a 1-bit codeword, a text dominated by one character, keeps the
+// generic kernel above).
+constexpr int kKeys8Items = 16;
+constexpr int kKeys8Tile = kBlock * kKeys8Items;
+constexpr int kKeys8MinLen = (kKeyBits + kKeys8Items) / (kKeys8Items + 1);
+__global__ __launch_bounds__(kBlock) void build_keys0_u8_kernel(const uint8_t *__restrict__ sym, size_t n, DevCode code,
+                                                                Key0 *__restrict__ keys, uint8_t *__restrict__ dig0) {
+  static_assert(sizeof(Key0) == 4, "register form of the key builder: 32-bit keys");
+  __shared__ uint32_t stab[256];  // (len << 16) | codeword
+  const int ub = code.uniform_bits > 0 ? code.uniform_bits : 0;
+  stab[threadIdx.x] = ub ? ((static_cast<uint32_t>(ub) << 16) | threadIdx.x)
+                         : ((static_cast<uint32_t>(code.len[threadIdx.x]) << 16) | code.cw[threadIdx.x]);
+  __syncthreads();
+  const size_t p0 = static_cast<size_t>(blockIdx.x) * kKeys8Tile + static_cast<size_t>(threadIdx.x) * kKeys8Items;
+  if (p0 >= n) return;
+  // (the symbol buffer is 256-byte aligned and padded by 16 bytes behind n; positions at or behind n count as symbol 0)
+  uint32_t w[8];
+  {
+    const uint4 a = *reinterpret_cast<const uint4 *>(sym + p0);
+    w[0] = a.x;
+    w[1] = a.y;
+    w[2] = a.z;
+    w[3] = a.w;
+    if (p0 + kKeys8Items <= n) {
+      const uint4 b = *reinterpret_cast<const uint4 *>(sym + p0 + kKeys8Items);
+      w[4] = b.x;
+      w[5] = b.y;
+      w[6] = b.z;
+      w[7] = b.w;
+    } else {
+      w[4] = w[5] = w[6] = w[7] = 0u;
+    }
+    if (p0 + 2 * kKeys8Items > n) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const size_t pos = p0 + 4 * static_cast<size_t>(q);
+        if (pos >= n) {
+          w[q] = 0u;
+        } else if (pos + 4 > n) {
+          w[q] &= (1u << (8 * static_cast<unsigned>(n - pos))) - 1u;
+        }
+      }
+    }
+  }
+  auto sym_at = [&](int t) { return (w[t >> 2] >> (8 * (t & 3))) & 0xffu; };  // (t: a compile-time constant everywhere)
+  uint32_t key = 0;
+  int used = 0;
+#pragma unroll
+  for (int t = kKeys8Items - 1; t < 2 * kKeys8Items; t++) {  // the key of the lane's last position
+    if (used < kKeyBits) {
+      const uint32_t e = stab[sym_at(t)];
+      const int l = static_cast<int>(e >> 16);
+      const int take = min(l, kKeyBits - used);
+      key = (take < 32 ? key << take : 0u) | ((e & 0xffffu) >> (l - take));
+      used += take;
+    }
+  }
+  uint32_t k[kKeys8Items];
+  k[kKeys8Items - 1] = key;
+#pragma unroll
+  for (int j = kKeys8Items - 2; j >= 0; j--) {  // key(i) = codeword(i) ++ key(i + 1)
+    const uint32_t e = stab[sym_at(j)];
+    const int l = static_cast<int>(e >> 16);
+    key = ((e & 0xffffu) << (kKeyBits - l)) | (key >> l);
+    k[j] = key;
+  }
+  if (p0 + kKeys8Items <= n) {
+#pragma unroll
+    for (int q = 0; q < kKeys8Items / 4; q++) {
+      *reinterpret_cast<uint4 *>(keys + p0 + 4 * q) = make_uint4(k[4 * q], k[4 * q + 1], k[4 * q + 2], k[4 * q + 3]);
+    }
+    if (dig0) {
+      uint32_t d[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        d[q] = (k[4 * q] & 0xffu) | ((k[4 * q + 1] & 0xffu) << 8) | ((k[4 * q + 2] & 0xffu) << 16) | (k[4 * q + 3] << 24);
+      }
+      *reinterpret_cast<uint4 *>(dig0 + p0) = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kKeys8Items; j++) {
+      if (p0 + j < n) {
+        keys[p0 + j] = k[j];
+        if (dig0) dig0[p0 + j] = static_cast<uint8_t>(k[j]);
+      }
     }
   }
 }

@@ -31,6 +31,7 @@
 #include "radix_sort.h"
 #include "scanline.h"
 #include "suffix_array.h"
+#include "trie.h"
 #include "vocab.h"
 #include "walk.h"
 
@@ -144,11 +145,19 @@ struct Context {
   hipEvent_t evs[3] = {};         // fork / join / scalars fetched
   // vocab tables on the device
   uint32_t *d_stream = nullptr, *d_elig_start = nullptr, *d_elig_info = nullptr, *d_soft = nullptr;
+  uint32_t *d_vocab_word_idx = nullptr, *d_vocab_word_bits = nullptr;  // the vocabulary's words of the alphabet bitmap
+  uint8_t *d_cls_bmp = nullptr;                                         // class byte of every BMP code point
+  uint32_t *d_lt_chain_len = nullptr, *d_lt_chain_off = nullptr, *d_lt_child_begin = nullptr, *d_lt_child_cp = nullptr,
+           *d_lt_child_node = nullptr, *d_elig_node = nullptr, *d_elig_subtree = nullptr;  // the token trie (vocab.h, trie.h)
   int32_t *d_elig_id = nullptr, *d_tok_len = nullptr;
   unsigned long long *d_trie_key = nullptr;  // the fast path's token trie (vocab.h)
   uint32_t *d_trie_child = nullptr;
   int32_t *d_trie_id = nullptr;
   DeviceBuffer text_buf, a_buf, b_buf, fmt_buf;  // fmt_buf: id text of encodeExternal
+  // wp_linear_encode_batch: second text buffer, two id staging buffers and the copy streams of the shard pipeline
+  DeviceBuffer text_buf2, ids_stage[2];
+  hipStream_t up_stream = nullptr, down_stream = nullptr;
+  hipEvent_t pipe_ev[4] = {};  // ids staged [2], ids downloaded [2]
   uint32_t *d_used = nullptr, *d_lut = nullptr, *d_scan_tmp = nullptr;  // bitmap of the code points in use (kCpWords), lut (kCpTableSize), per-word prefixes (kCpWords)
   uint32_t *d_scalars = nullptr;                                         // kScalars words of device scalars
   uint8_t *d_code = nullptr;     // symbol code tables: cw u16[256] | len u8[256] | bmask u16[4096]
@@ -222,7 +231,12 @@ static void free_vocab_tables(Context *c) {
                    reinterpret_cast<void **>(&c->d_elig_info), reinterpret_cast<void **>(&c->d_soft),
                    reinterpret_cast<void **>(&c->d_elig_id), reinterpret_cast<void **>(&c->d_tok_len),
                    reinterpret_cast<void **>(&c->d_trie_key), reinterpret_cast<void **>(&c->d_trie_child),
-                   reinterpret_cast<void **>(&c->d_trie_id)}) {
+                   reinterpret_cast<void **>(&c->d_trie_id), reinterpret_cast<void **>(&c->d_vocab_word_idx),
+                   reinterpret_cast<void **>(&c->d_vocab_word_bits), reinterpret_cast<void **>(&c->d_cls_bmp),
+                   reinterpret_cast<void **>(&c->d_lt_chain_len), reinterpret_cast<void **>(&c->d_lt_chain_off),
+                   reinterpret_cast<void **>(&c->d_lt_child_begin), reinterpret_cast<void **>(&c->d_lt_child_cp),
+                   reinterpret_cast<void **>(&c->d_lt_child_node), reinterpret_cast<void **>(&c->d_elig_node),
+                   reinterpret_cast<void **>(&c->d_elig_subtree)}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -252,6 +266,16 @@ static void destroy_context(Context *c) {
   c->a_buf.release();
   c->b_buf.release();
   c->fmt_buf.release();
+  c->text_buf2.release();
+  c->ids_stage[0].release();
+  c->ids_stage[1].release();
+  for (auto &e : c->pipe_ev) {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
+  if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+  if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
+  c->up_stream = c->down_stream = nullptr;
   for (auto &e : c->ev) {
     if (e) (void)hipEventDestroy(e);
     e = nullptr;
@@ -291,6 +315,9 @@ static std::vector<std::unique_ptr<Context>> &context_pool() {
 }
 
 static void release_arenas(Context *c) {
+  c->text_buf2.release();
+  c->ids_stage[0].release();
+  c->ids_stage[1].release();
   c->text_buf.release();
   c->a_buf.release();
   c->b_buf.release();
@@ -306,7 +333,10 @@ static void park_context(std::unique_ptr<Context> c) {
   (void)hipSetDevice(c->device);
   if (!no_pool && hipStreamSynchronize(c->stream) == hipSuccess && hipStreamSynchronize(c->stream2) == hipSuccess) {
     free_vocab_tables(c.get());
-    if (c->text_buf.cap + c->a_buf.cap + c->b_buf.cap + c->fmt_buf.cap > kPoolArenaBytes) release_arenas(c.get());
+    if (c->text_buf.cap + c->text_buf2.cap + c->ids_stage[0].cap + c->ids_stage[1].cap + c->a_buf.cap + c->b_buf.cap + c->fmt_buf.cap >
+        kPoolArenaBytes) {
+      release_arenas(c.get());
+    }
     c->d_ids = nullptr;
     c->dbg = {};
     std::lock_guard<std::mutex> g(g_pool_mu);
@@ -325,6 +355,16 @@ static void upload_vocab_tables(Context *c, const HostVocab &hv) {
   c->d_elig_id = upload(hv.elig_id, c->stream);
   c->d_tok_len = upload(hv.tok_len, c->stream);
   c->d_soft = upload(hv.soft, c->stream);
+  c->d_vocab_word_idx = upload(hv.used_word_idx, c->stream);
+  c->d_vocab_word_bits = upload(hv.used_word_bits, c->stream);
+  c->d_cls_bmp = upload(hv.cls_bmp, c->stream);
+  c->d_lt_chain_len = upload(hv.lt_chain_len, c->stream);
+  c->d_lt_chain_off = upload(hv.lt_chain_off, c->stream);
+  c->d_lt_child_begin = upload(hv.lt_child_begin, c->stream);
+  c->d_lt_child_cp = upload(hv.lt_child_cp, c->stream);
+  c->d_lt_child_node = upload(hv.lt_child_node, c->stream);
+  c->d_elig_node = upload(hv.elig_node, c->stream);
+  c->d_elig_subtree = upload(hv.elig_subtree, c->stream);
   {
     std::vector<unsigned long long> tk(hv.trie_key.begin(), hv.trie_key.end());
     c->d_trie_key = upload(tk, c->stream);
@@ -426,6 +466,7 @@ static void encode_on_device(const wp_vocab *v, Context *c, const uint8_t *d_tex
   c->rstats.passes = 0;
   c->rstats.elems = 0;
   c->rstats.digit_bytes = 0;
+  c->rstats.bytes = 0;
   c->rstats.spans.on = v->stage_timing;
   c->rstats.spans.used = 0;
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[0], st));
@@ -452,8 +493,8 @@ static void encode_on_device(const wp_vocab *v, Context *c, const uint8_t *d_tex
   // does the text itself hold code point 0 or 1 (the separator)?  (read before the vocab marks its symbols)
   // (bits 0 and 1 of the first bitmap word)
   WP_HIP(hipMemcpyAsync(c->d_scalars + 20, c->d_used, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-  hipLaunchKernelGGL(mark_used_kernel, dim3(cdiv(std::max<size_t>(hv.stream.size(), 1), kBlock)), dim3(kBlock), 0,
-                     st, c->d_stream, hv.stream.size(), c->d_used);
+  hipLaunchKernelGGL(vocab_alphabet_kernel, dim3(cdiv(hv.used_word_idx.size(), kBlock)), dim3(kBlock), 0, st,
+                     c->d_vocab_word_idx, c->d_vocab_word_bits, static_cast<uint32_t>(hv.used_word_idx.size()), c->d_used);
   // alphabet: bitmap -> per-word prefixes + sigma -> lut (dense symbol of a used code point c = lut[c] + 1)
   hipLaunchKernelGGL(alphabet_prefix_kernel, dim3(1), dim3(kAlphaThreads), 0, st, c->d_used, c->d_scan_tmp, c->d_scalars + 1);
   hipLaunchKernelGGL(alphabet_lut_kernel, dim3(kCpTableSize / kBlock), dim3(kBlock), 0, st, c->d_used, c->d_scan_tmp, c->d_lut);
@@ -535,6 +576,13 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   // digit bytes (radix_sort.h): the round-0 sort's histograms read 1 byte per key instead of 8
   static const bool env_no_digit_bytes = env_flag("WP_NO_DIGIT_BYTES");
   const bool use_digit_bytes = !env_no_digit_bytes && kRadixBits <= 8 && n > kRadixSmallN;
+  // text-only layout: the needed groups are resolved along the token trie (trie.h) instead of by doubling rounds
+  // (env WP_DOUBLING_ROUNDS=1 keeps the rounds: the A/B switch of this round's change)
+  static const bool env_doubling = env_flag("WP_DOUBLING_ROUNDS");
+  const bool use_trie = text_only && !full && M > 0 && !env_doubling && !env_flag("WP_NO_PRUNE");
+  S.trie_refine = use_trie ? 1 : 0;
+  uint32_t *d_node_of_slot = nullptr, *d_child_sym = nullptr, *d_gnode = nullptr, *d_gdone = nullptr;
+  SymT *d_vsym = nullptr;
   SymT *d_sym = nullptr;
   uint8_t *DG0 = nullptr, *DG1 = nullptr, *d_rng_long = nullptr;
   uint32_t *d_rng_lo = nullptr, *d_rng_hi = nullptr;
@@ -577,7 +625,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     AS0 = ar.take<uint32_t>(n);
     AS1 = ar.take<uint32_t>(n);
     AG = ar.take<uint32_t>(n);
-    d_sa = (v->keep_debug || v->lcp_kasai || text_only) ? ar.take<uint32_t>(n) : nullptr;
+    d_sa = (v->keep_debug || v->lcp_kasai || (text_only && !use_trie)) ? ar.take<uint32_t>(n) : nullptr;
     d_rng_lo = ar.take<uint32_t>(M + 1);
     d_rng_hi = ar.take<uint32_t>(M + 1);
     d_rng_long = ar.take<uint8_t>(M + 1);
@@ -587,10 +635,15 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     d_tdep = ar.take<uint32_t>(n + 2 + rr_tiles * 4 + 8);  // (tail: look-back state of the fused rerank)
     d_gdepth = ar.take<uint32_t>(n);
     d_lcp = (text_only && !v->keep_debug) ? nullptr : ar.take<int32_t>(n);  // (text-only layout: nothing reads the LCPs)
+    d_node_of_slot = use_trie ? ar.take<uint32_t>(n) : nullptr;  // end node of the suffix in a slot of a needed group (trie.h)
+    d_vsym = use_trie ? ar.take<SymT>(hv.stream.size() + 16) : nullptr;
+    d_child_sym = use_trie ? ar.take<uint32_t>(hv.lt_child_cp.size() + 1) : nullptr;
     d_radix_tmp = ar.take<uint32_t>(radix_words);
     d_ghead = ar.take<uint32_t>(n / 2 + 4);
-    d_large_id = ar.take<uint32_t>(n / 2 + 4);
-    d_large_off = ar.take<uint32_t>(n / 2 + 4);
+    d_large_id = ar.take<uint32_t>(static_cast<size_t>(M) + 4);   // per needed group (at most one per long token): first slot,
+    d_large_off = ar.take<uint32_t>(static_cast<size_t>(M) + 4);  // depth,
+    d_gnode = ar.take<uint32_t>(static_cast<size_t>(M) + 4);      // trie node its members share and the symbols behind it (trie.h)
+    d_gdone = ar.take<uint32_t>(static_cast<size_t>(M) + 4);
     d_lg_head = ar.take<uint32_t>(n / kLsMaxGroup + 4);
     d_lg_off = ar.take<uint32_t>(n / kLsMaxGroup + 4);
     LK1 = ar.take<uint64_t>(n);
@@ -661,7 +714,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
                           c->code_bits == bits && c->code_lo == lo_bits && c->code_uses < kCodeReuse;
   if (!reuse_code) WP_HIP(hipMemsetAsync(c->d_symhist, 0, sizeof(uint32_t) * 256, st));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(decode_write_kernel<SymT>), dim3(cdiv(nbytes, kDecTile)), dim3(kBlock), 0, st,
-                     d_text, nbytes, d_tile_prefix, c->d_lut, d_sym, d_cls, d_cps, c->d_soft,
+                     d_text, nbytes, d_tile_prefix, c->d_lut, d_sym, d_cls, d_cps, c->d_cls_bmp, c->d_soft,
                      static_cast<int>(hv.soft.size()), allow_variable && !reuse_code ? c->d_symhist : nullptr, lo_bits);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(map_vocab_symbols_kernel<SymT>), dim3(cdiv(n - n_text, kBlock)), dim3(kBlock), 0,
                      st, c->d_stream, n_text, n, c->d_lut, d_sym);
@@ -707,8 +760,18 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     WP_HIP(hipMemcpyAsync(c->d_code, c->h_code, blob_bytes, hipMemcpyHostToDevice, st));
   }
   S.symbols_per_key = static_cast<int32_t>(kKeyBits / std::max(1.0, code.avg_bits));
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(build_keys0_kernel<SymT>), dim3(cdiv(n, kKeyTile)), dim3(kBlock), 0, st, d_sym,
-                     n, dcode, reinterpret_cast<Key0 *>(K0), DG0);
+  {
+    // 8-bit symbols with no codeword shorter than kKeys8MinLen bits (every ordinary text): the register form
+    int min_len = code.uniform_bits ? code.uniform_bits : 99;
+    for (uint8_t l : code.len) min_len = std::min<int>(min_len, l);
+    if (sizeof(SymT) == 1 && sizeof(Key0) == 4 && min_len >= kKeys8MinLen && !env_flag("WP_KEYS_GENERIC")) {
+      hipLaunchKernelGGL(build_keys0_u8_kernel, dim3(cdiv(n, kKeys8Tile)), dim3(kBlock), 0, st,
+                         reinterpret_cast<const uint8_t *>(d_sym), n, dcode, reinterpret_cast<Key0 *>(K0), DG0);
+    } else {
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(build_keys0_kernel<SymT>), dim3(cdiv(n, kKeyTile)), dim3(kBlock), 0, st, d_sym,
+                         n, dcode, reinterpret_cast<Key0 *>(K0), DG0);
+    }
+  }
   WP_LAUNCH_CHECK();
   if (v->stage_timing) WP_HIP(hipEventRecord(c->ev[2], st));
 
@@ -738,7 +801,8 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       const int hb = bit_length(n - 1);
       // (the top bits of a text position are uniformly distributed: histogram by LDS atomics)
       const int bc = radix_sort_pairs<uint32_t>(dst, val, t_dst, t_val, m, std::max(0, hb - bin_bits), hb, d_radix_tmp,
-                                                radix_words, st, nullptr, false, hb + 1);
+                                                radix_words, st, nullptr, false, hb + 1, DigitBytes(),
+                                                static_cast<const PlainVals *>(nullptr), true);
       hipLaunchKernelGGL(scatter_pairs_kernel, dim3(cdiv(m, kSpTile)), dim3(kBlock), 0, st, bc ? t_dst : dst,
                          bc ? t_val : val, m, d_rank, n, 1);
     } else {
@@ -778,8 +842,11 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       d1.tail_mask = (1u << (hb_n - mid)) - 1u;
     }
     // (the roofline statistics describe the plain scatter: the instantiation that also computes the ranks is another kernel)
+    // (val == nullptr without a rank source: the values are the slots themselves, made up by the pass.  The digits of
+    // both passes are position bits, uniform over 64..128 values: LDS atomics into interleaved copies of the counters)
     radix_sort_pairs<uint32_t, RankVals>(dst, val, a_dst, a_val, n, kWinBits, mid, d_radix_tmp, radix_words, st,
-                                         rank_in_pass ? nullptr : &c->rstats, false, hb_n + 1, d1, rank_in_pass);
+                                         rank_in_pass ? nullptr : &c->rstats, val == nullptr && !rank_in_pass, 0, d1, rank_in_pass,
+                                         true);
     S.rank_in_pass = rank_in_pass ? 1 : 0;
     if (before_second) before_second();
     const uint32_t *f_dst = a_dst, *f_val = a_val;
@@ -789,7 +856,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       d2.dg1 = dig ? dig : nullptr;
       d2.dg0_ready = dig != nullptr;
       radix_sort_pairs<uint32_t>(a_dst, a_val, b_dst, b_val, n, mid, hb_n, d_radix_tmp, radix_words, st, &c->rstats,
-                                 false, hb_n + 1, d2);
+                                 false, 0, d2);
       f_dst = b_dst;
       f_val = b_val;
     }
@@ -813,7 +880,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   // (round-0 keys of up to 32 bits live as uint32 in the first half of the 64-bit key buffers)
   int cur = radix_sort_pairs<Key0>(reinterpret_cast<Key0 *>(K0), V0, reinterpret_cast<Key0 *>(K1), V1, n, 0, kKeyBits,
                                    d_radix_tmp, radix_words, st, &c->rstats, true, code.uniform_bits ? 0 : hist_atomic_bits,
-                                   db);
+                                   db, static_cast<const PlainVals *>(nullptr), true);
   Key0 *keys = reinterpret_cast<Key0 *>(cur ? K1 : K0);
   S.key_bits = kKeyBits;
   uint32_t *vals = cur ? V1 : V0, *other_vals = cur ? V0 : V1;
@@ -854,6 +921,11 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
                     reinterpret_cast<unsigned long long *>(c->d_scalars + 4),
                     text_only && !v->keep_debug ? d_sa : nullptr, need_depth, d_claim_need, d_gclaim, d_gneed0};
       WP_HIP(hipMemsetAsync(d_claim_need, 0, claim_size * sizeof(uint32_t), st2));
+      if (use_trie) {  // the vocabulary stream and the trie's child labels as dense symbols of this encode's alphabet
+        const size_t ns = hv.stream.size(), nc = hv.lt_child_cp.size();
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(trie_map_symbols_kernel<SymT>), dim3(cdiv(std::max<size_t>(std::max(ns, nc), 1), kBlock)),
+                           dim3(kBlock), 0, st2, c->d_stream, ns, c->d_lt_child_cp, nc, c->d_lut, d_vsym, d_child_sym);
+      }
       if (M > 0) {  // (no eligible token at all: every tied group retires)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(need_groups_kernel<SymT>), dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)),
                            dim3(kBlock), 0, st2, keys, vals, n, d_sym, c->d_stream, c->d_elig_start, c->d_elig_info, M,
@@ -864,6 +936,11 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       if (M > 0) {
         hipLaunchKernelGGL(needed_need_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st2, nl);  // (a needed group per token at most)
         hipLaunchKernelGGL(needed_fill_kernel, dim3(1024), dim3(kBlock), 0, st2, nl, vals, n);
+        if (use_trie) {
+          const TokenTrie tt{c->d_lt_chain_len, c->d_lt_chain_off, c->d_lt_child_begin, c->d_lt_child_node, d_child_sym};
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(trie_group_start_kernel<SymT>), dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st2, vals,
+                             d_large_id, d_large_off, c->d_scalars + 4, d_sym, n, d_vsym, tt, d_gnode, d_gdone);
+        }
       }
       if (fuse_rank) {
         // (the ranks are computed inside the first partition pass of the rank store, below)
@@ -900,7 +977,15 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
                          slots, other_vals, AG, adep, d_ghead, d_gdepth, c->d_scalars + 4);
     }
     fork();
-    if (fuse_rank) {
+    if (fuse_rank && use_trie) {
+      // Trie refinement: nobody asks for a group's head or depth — the step functions change at boundaries between
+      // distinct keys only (short tokens) or inside needed groups (long tokens, resolved by the trie round, which stores
+      // every rank it touches), so a suffix's own slot serves as its rank: the first partition pass makes the slot
+      // column up (the identity) instead of deriving group heads from the sorted keys.
+      store_ranks_round0(vals, nullptr, LV0, LV1, reinterpret_cast<uint32_t *>(hd) + ((n + 3) & ~static_cast<size_t>(3)),
+                         reinterpret_cast<uint32_t *>(keys), DG0 ? db.tail_out(cur) : nullptr,
+                         DG0 ? db.tail_out(cur ^ 1) : nullptr, nullptr, [&] { join(); });
+    } else if (fuse_rank) {
       // pair a = large-group buffers (idle in round 0), pair b = behind hd and the key buffer, which the side
       // stream's searches and the first pass itself still read until the join
       const RankVals rv{keys, dcode.first_len, dcode.uniform_bits, d_gdepth};
@@ -920,7 +1005,9 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   }
   uint32_t *avals = other_vals;  // active list values live in the vals buffer the sort did not end in
   uint32_t *spare_vals = vals;
-  const int rb = bit_length(n);  // rank+1 <= n
+  // second keys of a round: 1 + rank (<= n), or — trie refinement — 1 + trie node
+  const int rb = use_trie ? bit_length(hv.lt_chain_len.size() + 1) : bit_length(n);
+  const TokenTrie trie{c->d_lt_chain_len, c->d_lt_chain_off, c->d_lt_child_begin, c->d_lt_child_node, d_child_sym};
   // Between two rounds the host needs the new list sizes (grids, large-group path).  The copy of the
   // scalars and the LDS segmented sort of the next round are queued first — the sort reads its sizes on
   // the device and gets a grid for the largest possible list — and only then does the host wait for the
@@ -928,10 +1015,15 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   auto next_round_begin = [&](size_t upper) {
     WP_HIP(hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(uint32_t) * 12, hipMemcpyDeviceToHost, st));
     WP_HIP(hipEventRecord(c->evs[2], st));
+    if (upper > 0 && use_trie) {  // every list entry walks the token trie: its end node is its second key (in adep)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(trie_walk_kernel<SymT>), dim3(std::min<size_t>(cdiv(upper, kBlock), 16384)), dim3(kBlock), 0,
+                         st, avals, AG, d_gnode, d_gdone, c->d_scalars + 4, d_sym, n, d_vsym, trie, adep);
+    }
     fork();  // the large-group path of the next round (side stream) may start from here
     if (upper > 0) {
       hipLaunchKernelGGL(local_sort_kernel, dim3(cdiv(upper, kLsT)), dim3(kBlock), 0, st, avals, AG, adep,
-                         c->d_scalars + 4, d_ghead, d_rank, n, rb, K0, spare_vals);
+                         c->d_scalars + 4, d_ghead, d_rank, n, rb, K0, spare_vals,
+                         use_trie ? adep : static_cast<const uint32_t *>(nullptr));
     }
     WP_HIP(hipEventSynchronize(c->evs[2]));
   };
@@ -957,10 +1049,13 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   // behind a pruned round 0 every group carries the depth its own tokens need (DepthRule, prune.h)
   static const bool env_global_need = env_flag("WP_GLOBAL_NEED");
   uint32_t *gneed_cur = d_gneed0, *gneed_nxt = d_gneed1;
-  const bool group_need = prune && M > 0 && !env_global_need;
+  const bool group_need = prune && M > 0 && !env_global_need && !use_trie;
   while (n_act > 0) {
     DepthRule rrule = rule;
-    if (group_need) {
+    if (use_trie) {  // one split by the trie nodes resolves every needed group
+      rrule.final_round = 1;
+      rrule.second_out = d_node_of_slot;
+    } else if (group_need) {
       rrule.gneed_in = gneed_cur;
       rrule.gneed_out = gneed_nxt;
       std::swap(gneed_cur, gneed_nxt);
@@ -983,7 +1078,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       const int lgb = bit_length(n_large_groups > 0 ? n_large_groups - 1 : 0);
       hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(cdiv(n_large, kLxSpan), kBlock / kWave)), dim3(kBlock), 0, st2,
                          avals, adep, d_lg_head, d_lg_off, static_cast<uint32_t>(n_large_groups), n_large, d_rank, n, rb,
-                         K1, LV0, LPOS);
+                         K1, LV0, LPOS, use_trie ? adep : static_cast<const uint32_t *>(nullptr));
       const int lc = radix_sort_pairs<uint64_t>(K1, LV0, LK1, LV1, n_large, 0, rb + lgb, d_radix_tmp, radix_words, st2,
                                                 nullptr);  // (the roofline statistics describe the round-0 sort only)
       hipLaunchKernelGGL(large_writeback_kernel, dim3(std::min<size_t>(cdiv(n_large, kBlock), 8192)), dim3(kBlock), 0,
@@ -1017,6 +1112,11 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
     fork();
     store_ranks(svals, hd, reinterpret_cast<uint32_t *>(hd) + n, reinterpret_cast<uint32_t *>(skeys), n_act);
     WP_LAUNCH_CHECK();
+    if (use_trie) {  // (nothing stays on the list)
+      join();
+      rounds++;
+      break;
+    }
     classified = classify_groups(n_act);
     join();
     std::swap(slots, other_slots);
@@ -1065,10 +1165,15 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       // S = text . 1: the reach of every token is its range in the sorted keys (prune.h); long tokens are
       // narrowed inside their refined group.  The marks arrive sorted (tokens in lexicographic order).
       if (M > 0) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(long_token_range_kernel<SymT>), dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)),
-                           dim3(kBlock), 0, st, d_sa,
-                           d_sym, n, c->d_stream, c->d_elig_start, c->d_elig_info, M, c->d_lut, d_rng_lo, d_rng_hi,
-                           d_rng_long);
+        if (use_trie) {
+          hipLaunchKernelGGL(trie_token_range_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, d_node_of_slot, c->d_elig_node,
+                             c->d_elig_subtree, M, d_rng_lo, d_rng_hi, d_rng_long);
+        } else {
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(long_token_range_kernel<SymT>), dim3(cdiv(static_cast<size_t>(M) * kWave, kBlock)),
+                             dim3(kBlock), 0, st, d_sa,
+                             d_sym, n, c->d_stream, c->d_elig_start, c->d_elig_info, M, c->d_lut, d_rng_lo, d_rng_hi,
+                             d_rng_long);
+        }
         hipLaunchKernelGGL(virtual_marks_kernel, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, st, d_rng_lo, d_rng_hi, M,
                            c->d_elig_id, c->d_elig_info, d_mslot0, d_mid, d_minfo, d_rf, d_rb);
       }
@@ -1184,12 +1289,16 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       uint32_t *d_reach = LV0, *d_reach_tiles = LPOS;
       uint8_t *d_aflags = reinterpret_cast<uint8_t *>(LV1);
       const unsigned rtiles = cdiv(n_text, kReachTile), atiles = cdiv(n_text, kAnchorTile);
-      hipLaunchKernelGGL(reach_kernel, dim3(rtiles), dim3(kBlock), 0, st, wa, d_reach, d_reach_tiles);
-      hipLaunchKernelGGL(reach_spine_kernel, dim3(1), dim3(1024), 0, st, d_reach_tiles, static_cast<size_t>(rtiles));
       uint32_t *d_wp_tiles = d_reach_tiles + rtiles + 1;  // first word-prefix position at or behind each tile
       uint32_t *d_ns_tiles = d_wp_tiles + rtiles + 1;  // same for non-space positions
+      uint32_t *d_gap_a = d_ns_tiles + rtiles + 1, *d_gap_b = d_gap_a + rtiles + 1;  // where the coverage rule applies (walk.h)
+      // (the class-rule anchor list is still in d_anchors: the coverage rule is only needed inside its long gaps)
+      hipLaunchKernelGGL(gap_tiles_kernel, dim3(cdiv(rtiles, kBlock)), dim3(kBlock), 0, st, d_anchors, c->d_scalars + 10, n_text,
+                         rtiles, v->cover_anchors ? 1 : 0, d_gap_a, d_gap_b);
+      hipLaunchKernelGGL(reach_kernel, dim3(rtiles), dim3(kBlock), 0, st, wa, d_reach, d_reach_tiles, d_gap_a, d_gap_b);
+      hipLaunchKernelGGL(reach_spine_kernel, dim3(1), dim3(1024), 0, st, d_reach_tiles, static_cast<size_t>(rtiles));
       hipLaunchKernelGGL(cover_flags_kernel, dim3(rtiles), dim3(kBlock), 0, st, d_cls, d_reach, d_reach_tiles, n_text,
-                         d_aflags, d_wp_tiles, d_ns_tiles);
+                         d_aflags, d_wp_tiles, d_ns_tiles, d_gap_a, d_gap_b);
       hipLaunchKernelGGL(suffix_min_kernel, dim3(1), dim3(1024), 0, st, d_wp_tiles, static_cast<size_t>(rtiles));
       hipLaunchKernelGGL(suffix_min_kernel, dim3(1), dim3(1024), 0, st, d_ns_tiles, static_cast<size_t>(rtiles));
       hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, d_aflags, n_text,
@@ -1217,8 +1326,25 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
       int32_t *d_ctmp = reinterpret_cast<int32_t *>(K0);  // (the key buffers are free after the suffix sort)
       const int words = kWbWords;
       const unsigned sblocks = cdiv(acap, static_cast<size_t>(words));
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_balanced_kernel<WalkArgs, LinearStep>), dim3(sblocks), dim3(kBlock), 0, st, wa,
-                         d_anchors, c->d_scalars + 10, acap, d_ctmp, d_blk_cnt);
+      // stretches of more than kWideMin positions (class rule, hard spacing chars only: one word each) go to a whole
+      // wave each first (walk.h, wide walk); the large-group buffers of the suffix sort are free by now
+      const uint32_t *d_wide_cnt = nullptr;
+      if (S.anchor_mode == 0 && all_hard && !wa.aflags && max_anchor_gap > kWideMin && !env_flag("WP_NO_WIDE_WALK")) {
+        uint32_t *d_wide_list = LV0, *d_wcnt = LV1;
+        WP_HIP(hipMemsetAsync(c->d_scalars + 13, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(wide_collect_kernel, dim3(std::min<size_t>(cdiv(acap, kBlock), 2048)), dim3(kBlock), 0, st, d_anchors,
+                           c->d_scalars + 10, n_text, d_wide_list, c->d_scalars + 13);
+        hipLaunchKernelGGL(walk_wide_kernel, dim3(std::min<size_t>(cdiv(acap, kBlock / kWave), 8192)), dim3(kBlock), 0, st, wa,
+                           d_anchors, c->d_scalars + 10, d_wide_list, c->d_scalars + 13, d_wcnt);
+        d_wide_cnt = d_wcnt;
+      }
+      if (d_wide_cnt) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_balanced_kernel<WalkArgs, LinearStep, true>), dim3(sblocks), dim3(kBlock), 0, st, wa,
+                           d_anchors, c->d_scalars + 10, acap, d_ctmp, d_blk_cnt, d_wide_cnt);
+      } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_balanced_kernel<WalkArgs, LinearStep, false>), dim3(sblocks), dim3(kBlock), 0, st, wa,
+                           d_anchors, c->d_scalars + 10, acap, d_ctmp, d_blk_cnt, d_wide_cnt);
+      }
       device_exclusive_scan(d_blk_cnt, d_blk_off, sblocks, d_emit_tmp, c->d_scalars + 9, st);
       hipLaunchKernelGGL(emit_gather_kernel, dim3(sblocks), dim3(kBlock), 0, st, d_anchors, c->d_scalars + 10, acap, d_ctmp,
                          d_blk_cnt, d_blk_off, d_ids, words);
@@ -1268,6 +1394,7 @@ static void run_sa_and_beyond(const wp_vocab *v, Context *c, wp_stats &S, Arena 
   S.radix_passes = c->rstats.passes;
   S.radix_pass_elems = c->rstats.elems;
   S.radix_digit_bytes = c->rstats.digit_bytes;
+  S.radix_pass_bytes = c->rstats.bytes;
   if (v->stage_timing) {
     auto span = [&](int a, int b) {
       float ms = 0;
@@ -1377,7 +1504,7 @@ static void encode_fast_on_device(const wp_vocab *v, Context *c, const uint8_t *
   ar.arm(st);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(decode_write_kernel<uint32_t>), dim3(dec_tiles), dim3(kBlock), 0, st, d_text, nbytes,
                      d_tile_cnt, static_cast<const uint32_t *>(nullptr), static_cast<uint32_t *>(nullptr), d_cls, d_cps,
-                     static_cast<const uint32_t *>(nullptr), 0, static_cast<uint32_t *>(nullptr), 0);
+                     c->d_cls_bmp, static_cast<const uint32_t *>(nullptr), 0, static_cast<uint32_t *>(nullptr), 0);
   hipLaunchKernelGGL(fast_anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, n_text, d_anchor_cnt);
   device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st);
   hipLaunchKernelGGL(fast_anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, n_text, d_anchor_cnt, d_anchors);
@@ -1441,7 +1568,8 @@ static void encode_fast_on_device(const wp_vocab *v, Context *c, const uint8_t *
     const int words = kWbWords;
     const unsigned sblocks = cdiv(acap, static_cast<size_t>(words));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_balanced_kernel<FastArgs, FastStep>), dim3(sblocks), dim3(kBlock), 0, st, fa,
-                       d_anchors, c->d_scalars + 10, acap, d_lid, d_blk_cnt);  // (d_lid: the long-word id buffer, idle here)
+                       d_anchors, c->d_scalars + 10, acap, d_lid, d_blk_cnt,  // (d_lid: the long-word id buffer, idle here)
+                       static_cast<const uint32_t *>(nullptr));
     device_exclusive_scan(d_blk_cnt, d_blk_off, sblocks, d_emit_tmp, c->d_scalars + 9, st);
     hipLaunchKernelGGL(emit_gather_kernel, dim3(sblocks), dim3(kBlock), 0, st, d_anchors, c->d_scalars + 10, acap, d_lid,
                        d_blk_cnt, d_blk_off, d_ids, words);
@@ -1876,6 +2004,7 @@ void encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const std::vecto
     S.radix_passes += T.radix_passes;
     S.radix_pass_elems += T.radix_pass_elems;
     S.radix_digit_bytes += T.radix_digit_bytes;
+    S.radix_pass_bytes += T.radix_pass_bytes;
     S.ms_total = std::max(S.ms_total, T.ms_total);
     S.ms_decode = std::max(S.ms_decode, T.ms_decode);
     S.ms_sa = std::max(S.ms_sa, T.ms_sa);
@@ -1964,6 +2093,99 @@ int wp_reserve(wp_vocab *v, size_t nbytes) {
     c->a_buf.ensure(nbytes + nbytes / 512 + (size_t(1) << 20) + (v->keep_debug ? 4 * nbytes : 0));
     c->b_buf.ensure(108 * n + (v->keep_debug ? 4 * n : 0) + (size_t(64) << 20));
     PinnedBlock warm(nbytes + (size_t(1) << 20));  // about a quarter of an id per byte, 4 bytes each
+  });
+}
+
+// A sequence of shards through one handle as a pipeline: while shard i is on the GPU, shard i + 1 is uploaded (a
+// helper thread, its own stream, the second text buffer) and the ids of shard i - 1 are downloaded (their own
+// stream, out of a staging buffer — the next encode overwrites the arena the ids were produced in).  For one call
+// nothing can overlap the sort; for a corpus that arrives as shards (the reference's own encodeExternal batches,
+// linear.cpp:355-371; the per-GPU stream of a sharded run) host to host then costs what the device path costs.
+int wp_linear_encode_batch(wp_vocab *v, const char *const *texts, const size_t *nbytes, size_t n_texts, int32_t **ids,
+                           size_t *n_ids) {
+  return guarded([&] {
+    for (size_t i = 0; i < n_texts; i++) {
+      ids[i] = nullptr;
+      n_ids[i] = 0;
+    }
+    if (n_texts == 0) return;
+    const auto t_all = wp_clock::now();
+    Context *c = get_context(v);
+    if (!c->up_stream) {
+      WP_HIP(hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+      WP_HIP(hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
+      for (auto &e : c->pipe_ev) WP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    size_t longest = 0;
+    for (size_t i = 0; i < n_texts; i++) longest = std::max(longest, nbytes[i]);
+    c->text_buf.ensure(longest + 64);
+    c->text_buf2.ensure(longest + 64);
+    DeviceBuffer *tb[2] = {&c->text_buf, &c->text_buf2};
+    const int device = c->device;
+    // upload of shard i into its text buffer, on the upload stream, finished when the call returns
+    auto upload = [&](size_t i) -> std::string {
+      try {
+        if (nbytes[i] == 0) return "";
+        WP_HIP(hipSetDevice(device));
+        char *dst = static_cast<char *>(tb[i & 1]->p);
+        WP_HIP(hipMemsetAsync(dst + (nbytes[i] & ~static_cast<size_t>(15)), 0, 32, c->up_stream));
+        WP_HIP(hipMemcpyAsync(dst, texts[i], nbytes[i], hipMemcpyHostToDevice, c->up_stream));
+        WP_HIP(hipStreamSynchronize(c->up_stream));
+        return "";
+      } catch (const std::exception &e) {
+        return e.what()[0] ? e.what() : "upload failed";
+      }
+    };
+    std::string up_err = upload(0);
+    if (!up_err.empty()) throw HipError(up_err);
+    std::vector<PinnedBlock> blocks;  // (released to the caller only when every shard is through)
+    blocks.reserve(n_texts);
+    bool staged_pending[2] = {false, false};
+    wp_stats total{};
+    for (size_t i = 0; i < n_texts; i++) {
+      std::future<std::string> next_up;
+      if (i + 1 < n_texts) next_up = std::async(std::launch::async, upload, i + 1);
+      struct Wait {  // the helper must be done with the text buffers before anything unwinds
+        std::future<std::string> &f;
+        ~Wait() {
+          if (f.valid()) f.wait();
+        }
+      } wait_up{next_up};
+      size_t n = 0;
+      wp_stats st{};
+      if (nbytes[i]) encode_on_device(v, c, static_cast<const uint8_t *>(tb[i & 1]->p), nbytes[i], &n, st);
+      blocks.emplace_back(std::max<size_t>(n, 1) * sizeof(int32_t));
+      if (n) {
+        const int slot = static_cast<int>(i & 1);
+        if (staged_pending[slot]) WP_HIP(hipEventSynchronize(c->pipe_ev[2 + slot]));  // the download of shard i - 2 has left the staging buffer
+        c->ids_stage[slot].ensure(n * sizeof(int32_t));
+        WP_HIP(hipMemcpyAsync(c->ids_stage[slot].p, c->d_ids, n * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+        WP_HIP(hipEventRecord(c->pipe_ev[slot], c->stream));
+        WP_HIP(hipStreamWaitEvent(c->down_stream, c->pipe_ev[slot], 0));
+        WP_HIP(hipMemcpyAsync(blocks.back().p, c->ids_stage[slot].p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->down_stream));
+        WP_HIP(hipEventRecord(c->pipe_ev[2 + slot], c->down_stream));
+        staged_pending[slot] = true;
+        // (the next encode may overwrite the arena: the copy into the staging buffer is ordered in front of it on c->stream)
+      }
+      n_ids[i] = n;
+      total.n_bytes += st.n_bytes;
+      total.n_text += st.n_text;
+      total.n_total += st.n_total;
+      total.n_ids += st.n_ids;
+      total.ms_total += st.ms_total;
+      total.rounds = std::max(total.rounds, st.rounds);
+      if (next_up.valid()) {
+        up_err = next_up.get();
+        if (!up_err.empty()) throw HipError(up_err);
+      }
+    }
+    WP_HIP(hipStreamSynchronize(c->down_stream));
+    for (size_t i = 0; i < n_texts; i++) {
+      if (n_ids[i]) ids[i] = static_cast<int32_t *>(blocks[i].release());
+    }
+    v->stats = total;
+    v->stats.n_devices = 1;
+    v->stats.ms_host_total = ms_since(t_all);
   });
 }
 

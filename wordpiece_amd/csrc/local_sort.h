@@ -78,7 +78,10 @@ constexpr int kLxSpan = 64;  // (2048: 32 dependent gather rounds per wave, 94 u
 __global__ __launch_bounds__(kBlock) void large_extract_kernel(
     const uint32_t *__restrict__ aval, const uint32_t *__restrict__ adep, const uint32_t *__restrict__ lg_head,
     const uint32_t *__restrict__ lg_off, uint32_t n_lg, size_t n_large, const RankEntry *__restrict__ rank, size_t n,
-    int rbits, uint64_t *__restrict__ lkey, uint32_t *__restrict__ lval, uint32_t *__restrict__ lpos) {
+    int rbits, uint64_t *__restrict__ lkey, uint32_t *__restrict__ lval, uint32_t *__restrict__ lpos,
+    const uint32_t *__restrict__ second_key) {
+  // second_key != nullptr: the entries are sorted by second_key[list position] (trie.h: the end node of the suffix)
+  // instead of by the rank of the suffix `depth` symbols further on
   const int lane = lane_id();
   const size_t wave = static_cast<size_t>(blockIdx.x) * (kBlock / kWave) + wave_id();
   const size_t j0 = wave * kLxSpan;
@@ -95,8 +98,13 @@ __global__ __launch_bounds__(kBlock) void large_extract_kernel(
     while (j >= lg_off[i + 1]) i++;
     const uint32_t k = lg_head[i] + static_cast<uint32_t>(j - lg_off[i]);
     const uint32_t v = aval[k];
-    const size_t t = static_cast<size_t>(v) + adep[k];
-    const uint32_t r2 = t < n ? rank_of(rank[t]) + 1u : 0u;
+    uint32_t r2;
+    if (second_key) {
+      r2 = second_key[k] + 1u;
+    } else {
+      const size_t t = static_cast<size_t>(v) + adep[k];
+      r2 = t < n ? rank_of(rank[t]) + 1u : 0u;
+    }
     lkey[j] = (static_cast<uint64_t>(i) << rbits) | r2;
     lval[j] = v;
     lpos[j] = k;
@@ -128,7 +136,9 @@ __global__ __launch_bounds__(kBlock) void local_sort_kernel(const uint32_t *__re
                                                             const uint32_t *__restrict__ ghead,
                                                             const RankEntry *__restrict__ rank, size_t n, int rbits,
                                                             uint64_t *__restrict__ kout,
-                                                            uint32_t *__restrict__ vout) {
+                                                            uint32_t *__restrict__ vout,
+                                                            const uint32_t *__restrict__ second_key) {
+  // second_key: see large_extract_kernel
   // sizes_dev[0] = list length, sizes_dev[1] = number of groups: read on the device, so that the
   // kernel can be queued (with a grid for the largest possible list) while the host is still waiting
   // for the same numbers; workgroups behind the list leave at once
@@ -172,8 +182,13 @@ __global__ __launch_bounds__(kBlock) void local_sort_kernel(const uint32_t *__re
     val[r] = 0;
     if (r < nr && i < cnt) {
       const uint32_t v = aval[a + i];
-      const size_t t = static_cast<size_t>(v) + adep[a + i];
-      const uint64_t r2 = t < n ? rank_of(rank[t]) + 1u : 0u;
+      uint64_t r2;
+      if (second_key) {
+        r2 = static_cast<uint64_t>(second_key[a + i]) + 1u;
+      } else {
+        const size_t t = static_cast<size_t>(v) + adep[a + i];
+        r2 = t < n ? rank_of(rank[t]) + 1u : 0u;
+      }
       key[r] = (static_cast<uint64_t>(agid[a + i] - g_first) << rbits) | r2;
       val[r] = v;
     }

@@ -307,7 +307,10 @@ struct PlainVals {
   }
 };
 
-template <typename KeyT, int ITEMS, typename VS = PlainVals>
+// STABLE = false: the first pass of a sort has no earlier order to keep — equal digits may leave the tile in any
+// order — so a key takes its rank inside the wave from ONE LDS atomic on the wave's digit counter (the old value)
+// instead of the 8-ballot match-any (about 40 VALU instructions per key; DESIGN.md: the ranking is half of a pass).
+template <typename KeyT, int ITEMS, typename VS = PlainVals, bool STABLE = true>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const KeyT *__restrict__ kin, VS vs, KeyT *__restrict__ kout,
     uint32_t *__restrict__ vout, size_t n, int begin_bit, uint32_t mask,
@@ -355,7 +358,20 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     // out-of-range slots (only at the very end of the last tile) take the top bin: they are the
     // last keys in tile order, hence rank after every valid key and are never written back
     const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : (kRadixBins - 1);
-    rnk[r] = wave_rank_digit<kRadixBits>(mycnt, d, lane);
+    if (STABLE) {
+      rnk[r] = wave_rank_digit<kRadixBits>(mycnt, d, lane);
+    } else {
+      // (out-of-range slots of the last tile share the top bin with real keys here: they must still rank behind
+      // them, so they are counted after the loop)
+      rnk[r] = i < n ? atomicAdd(&wcnt[w][d], 1u) : 0u;
+    }
+  }
+  if (!STABLE && wave_base + static_cast<size_t>(ITEMS) * kWave > n) {  // (wave-uniform: the wave that holds the end)
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+      size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
+      if (i >= n) rnk[r] = atomicAdd(&wcnt[w][kRadixBins - 1], 1u);
+    }
   }
   __syncthreads();
   // thread t owns bins [t*kBinsPerThread, +kBinsPerThread): exclusive scan across waves, then bins
@@ -449,6 +465,8 @@ struct RadixStats {
   int passes = 0;
   long long elems = 0;
   long long digit_bytes = 0;  // digit bytes written by scatter launches (1 per element and launch)
+  long long bytes = 0;        // algorithmic bytes of the counted scatter launches: record read (without the index column
+                              // when the pass makes it up) + record written + digit byte written
   EventSpans spans;  // around every scatter launch
 };
 
@@ -497,7 +515,9 @@ template <typename KeyT, typename FV = PlainVals>
 int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, const BitRange *ranges,
                       int nranges, uint32_t *tmp, size_t tmp_words, hipStream_t st, RadixStats *stats,
                       bool identity_vals = false, int uniform_low_bits = 0, DigitBytes db = DigitBytes(),
-                      const FV *first_vals = nullptr) {
+                      const FV *first_vals = nullptr, bool input_order_free = false) {
+  // input_order_free: nothing depends on the order the input is in (a sort from scratch, NOT one pass of a sort that a
+  // caller runs as several calls, like the second partition pass of the rank store): the first pass may rank by atomics
   int cur = 0;
   if (n == 0) return cur;
   const bool small = n <= kRadixSmallN;
@@ -555,14 +575,19 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
       hipLaunchKernelGGL(radix_apply_kernel, dim3(nchunks), dim3(kRadixBins), 0, st, table, chunk_pre, ntiles);
     }
     if (stats) stats->spans.begin(st);
+    const bool made_up_index = identity_vals;
     const PlainVals vsrc{identity_vals ? static_cast<const uint32_t *>(nullptr) : vi};
     if (small) {
       if (first_vals) throw std::logic_error("radix_sort_ranges: a value source needs the full-size configuration");
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kSmallItems, PlainVals>), dim3(ntiles),
                          dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
     } else if (first_vals && pi == 0) {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, FV>), dim3(ntiles),
+      if (!input_order_free) throw std::logic_error("radix_sort_ranges: a value source is the first pass of a sort from scratch");
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, FV, false>), dim3(ntiles),
                          dim3(kBlock), 0, st, ki, *first_vals, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
+    } else if (pi == 0 && input_order_free) {  // (no earlier order to keep: ranks by LDS atomics)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, PlainVals, false>), dim3(ntiles),
+                         dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
     } else {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, PlainVals>), dim3(ntiles),
                          dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
@@ -574,6 +599,7 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
       stats->passes++;
       stats->elems += static_cast<long long>(n);
       if (dgo) stats->digit_bytes += static_cast<long long>(n);
+      stats->bytes += static_cast<long long>(n) * static_cast<long long>(2 * sizeof(KeyT) + 4 + (made_up_index ? 0 : 4) + (dgo ? 1 : 0));
     }
     cur ^= 1;
   }
@@ -583,10 +609,11 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
 template <typename KeyT, typename FV = PlainVals>
 int radix_sort_pairs(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, int begin_bit, int end_bit,
                      uint32_t *tmp, size_t tmp_words, hipStream_t st, RadixStats *stats, bool identity_vals = false,
-                     int uniform_low_bits = 0, DigitBytes db = DigitBytes(), const FV *first_vals = nullptr) {
+                     int uniform_low_bits = 0, DigitBytes db = DigitBytes(), const FV *first_vals = nullptr,
+                     bool input_order_free = false) {
   BitRange r{begin_bit, end_bit};
   return radix_sort_ranges<KeyT, FV>(k0, v0, k1, v1, n, &r, 1, tmp, tmp_words, st, stats, identity_vals,
-                                     uniform_low_bits, db, first_vals);
+                                     uniform_low_bits, db, first_vals, input_order_free);
 }
 
 }  // namespace wp

@@ -44,10 +44,15 @@ struct DepthRule {
   // (nullptr: `need` for everyone), gneed_out: by the new group ids.
   const uint32_t *gneed_in;
   uint32_t *gneed_out;
+  // final round (trie.h): the second keys are trie nodes, not ranks — every group retires after this split, no depth is
+  // looked up, and second_out[slot] receives the entry's second key (ascending inside a group)
+  int final_round;
+  uint32_t *second_out;
 };
 
 // old_gid: group of the entry in the list being split (high word of its key in rounds >= 1)
 __device__ __forceinline__ bool rr_stays_active(const DepthRule &rule, uint32_t nd, uint32_t old_gid) {
+  if (rule.final_round) return false;
   if (rule.full) return true;
   return nd < (rule.gneed_in ? rule.gneed_in[old_gid] : rule.need);
 }
@@ -101,10 +106,14 @@ __global__ __launch_bounds__(kBlock) void rerank_agg_kernel(const uint64_t *__re
         } else {
           // the second key is 1 + rank of suffix vals[k] + d (0: past the end), i.e. 1 + the first slot of
           // that suffix's group, where its depth is kept: no need to go through rank[] again
-          const uint32_t d = adep[k];
-          const uint32_t r2 = static_cast<uint32_t>(keys[k]);
-          const uint32_t dj = r2 ? gdepth[r2 - 1u] : 0u;
-          nd = min(d + dj, 0x7fffffffu);
+          if (rule.final_round) {
+            nd = 0u;
+          } else {
+            const uint32_t d = adep[k];
+            const uint32_t r2 = static_cast<uint32_t>(keys[k]);
+            const uint32_t dj = r2 ? gdepth[r2 - 1u] : 0u;
+            nd = min(d + dj, 0x7fffffffu);
+          }
         }
         tdep[k] = nd;
         act = rr_stays_active(rule, nd, ROUND0 ? 0u : static_cast<uint32_t>(keys[k] >> 32));
@@ -364,6 +373,8 @@ __device__ __forceinline__ void rr_first_half(RrTile &T, const uint64_t *__restr
           nd = tdep[k];
         } else if (ROUND0) {
           nd = static_cast<uint32_t>(count_key_symbols(me, kKeyBits, s_fl, uniform_bits));
+        } else if (rule.final_round) {
+          nd = 0u;
         } else {
           const uint32_t d = adep[k];
           const uint32_t r2 = static_cast<uint32_t>(me);
@@ -434,10 +445,12 @@ __device__ __forceinline__ void rr_second_half(const RrTile &T, const uint64_t *
       // the suffix array itself is only kept for debug fetches / the Kasai kernel, and (text-only layout,
       // rounds >= 1) for the slots of the groups whose long tokens are located in it afterwards
       if (sa) sa[x] = v;
+      if (!ROUND0 && rule.second_out) rule.second_out[x] = static_cast<uint32_t>(T.mes[r]) - 1u;
       // new rank entry of suffix v, scattered to the rank table afterwards.  In rounds >= 1 the
       // first subgroup of an old group keeps its rank (its head is the old head): left unchanged.
+      // (final round behind a round 0 whose ranks are the suffixes' own slots, not group heads: every entry is stored)
       bool changed = true;
-      if (!ROUND0) changed = mine ? ((T.bos[r] >> hl) & 1ull) != 0 : chg1;
+      if (!ROUND0 && !rule.final_round) changed = mine ? ((T.bos[r] >> hl) & 1ull) != 0 : chg1;
       const uint32_t nd = single ? 0u : (ROUND0 ? (T.nds[r] & 0xffffu) : T.nds[r]);
       hd[k] = changed ? head_slot : kRankUnchanged;
       if (gd) {

@@ -55,7 +55,26 @@ struct HostVocab {
   std::vector<uint32_t> elig_info;   // len | class << 30  (class 1 = ## suffix token)
   std::vector<int32_t> tok_len;      // per vocab line
   std::vector<uint32_t> soft;        // sorted spacing chars occurring inside eligible multi-char tokens
+  // the vocabulary's share of the alphabet (linear.cpp:83-101: every token's code points and the separator 1 are
+  // symbols of S) as words of the used-code-point bitmap: index (code point >> 5) and bits, one entry per word
+  std::vector<uint32_t> used_word_idx, used_word_bits;
+  // class byte (common.h: space | spacing | soft | punct) of every code point of the BMP, soft flag included:
+  // the decode kernel's class lookup is one load instead of ~25 range compares and a search in `soft`
+  std::vector<uint8_t> cls_bmp;
   int64_t n_dup_eligible = 0;        // eligible tokens that repeat an earlier (class, word)
+
+  // ---- token trie of the Linear path (trie.h) --------------------------------------------------------------
+  // Every distinct prefix of an eligible token's word is a node (both classes in one trie: a token's reach does not
+  // depend on its class, linear.cpp:161-189 pushes both kinds on the same kind of stack).  Node ids are PREORDER
+  // numbers with children in code point order — the order `elig` is in — so the nodes below a token's node are
+  // the id range [elig_node, elig_node + elig_subtree): a suffix of the text has token t as a prefix exactly when
+  // the deepest node its symbols reach lies in t's range.  A node with exactly one child starts a unary chain (its
+  // only child is the next id); chains are walked 8 symbols per load against the token that runs through them.
+  std::vector<uint32_t> lt_chain_len;    // per node: nodes of the unary chain below it (0: leaf or branching node)
+  std::vector<uint32_t> lt_chain_off;    // per node: offset in `stream` of the chain's first label
+  std::vector<uint32_t> lt_child_begin;  // per node (+1): its children in lt_child_cp / lt_child_node
+  std::vector<uint32_t> lt_child_cp, lt_child_node;  // code point (ascending per node) and id of every child
+  std::vector<uint32_t> elig_node, elig_subtree;     // per eligible token (in `elig` order): its node and the nodes below it + 1
 
   // word_piece::fast (fast.cpp:22-36): the two word -> id maps as one trie stored in a hash table.
   // Node 0 / 1 = root of the prefix-class / ##-class tokens; every distinct prefix of an eligible
@@ -211,7 +230,98 @@ struct HostVocab {
     }
     std::sort(soft.begin(), soft.end());
     soft.erase(std::unique(soft.begin(), soft.end()), soft.end());
+    {
+      std::vector<uint32_t> cps(stream);
+      cps.push_back(1u);  // the separator
+      std::sort(cps.begin(), cps.end());
+      used_word_idx.clear();
+      used_word_bits.clear();
+      for (uint32_t c : cps) {
+        if (c >= kInvalidUnicode) continue;  // (malformed tokens keep the marker: never part of the alphabet)
+        if (used_word_idx.empty() || used_word_idx.back() != (c >> 5)) {
+          used_word_idx.push_back(c >> 5);
+          used_word_bits.push_back(0u);
+        }
+        used_word_bits.back() |= 1u << (c & 31u);
+      }
+    }
+    cls_bmp.assign(0x10000, 0);
+    for (uint32_t c = 0; c < 0x10000; c++) {
+      uint8_t f = 0;
+      if (is_space(c)) f |= kClsSpace;
+      if (is_punctuation(c)) f |= kClsPunct;
+      if (is_spacing_char(c)) f |= kClsSpacing;
+      cls_bmp[c] = f;
+    }
+    for (uint32_t c : soft) {
+      if (c < 0x10000) cls_bmp[c] |= kClsSoft;
+    }
     build_trie();
+    build_token_trie();
+  }
+
+  // the eligible tokens come in lexicographic order, so the trie is built along the current path (a stack): the
+  // nodes are created in preorder, a node's subtree is closed when the path leaves it
+  void build_token_trie() {
+    const size_t E = elig_id.size();
+    std::vector<uint32_t> depth{0}, nchild{0}, creator{0}, size{0};
+    std::vector<uint32_t> edge_parent, edge_cp, edge_node;
+    std::vector<uint32_t> path{0};
+    elig_node.assign(E, 0);
+    elig_subtree.assign(E, 0);
+    const std::vector<uint32_t> *prev = nullptr;
+    for (size_t k = 0; k < E; k++) {
+      const std::vector<uint32_t> &w = tokens[static_cast<size_t>(elig_id[k])].word;
+      size_t l = 0;
+      if (prev) {
+        while (l < prev->size() && l < w.size() && (*prev)[l] == w[l]) l++;
+      }
+      while (path.size() - 1 > l) {
+        const uint32_t x = path.back();
+        path.pop_back();
+        size[x] = static_cast<uint32_t>(depth.size()) - x;
+      }
+      for (size_t j = l; j < w.size(); j++) {
+        const uint32_t id = static_cast<uint32_t>(depth.size()), parent = path.back();
+        depth.push_back(static_cast<uint32_t>(j + 1));
+        nchild.push_back(0);
+        creator.push_back(static_cast<uint32_t>(k));
+        size.push_back(0);
+        nchild[parent]++;
+        edge_parent.push_back(parent);
+        edge_cp.push_back(w[j]);
+        edge_node.push_back(id);
+        path.push_back(id);
+      }
+      elig_node[k] = path.back();
+      prev = &w;
+    }
+    const uint32_t N = static_cast<uint32_t>(depth.size());
+    while (!path.empty()) {
+      size[path.back()] = N - path.back();
+      path.pop_back();
+    }
+    for (size_t k = 0; k < E; k++) elig_subtree[k] = size[elig_node[k]];
+    lt_child_begin.assign(static_cast<size_t>(N) + 1, 0);
+    for (uint32_t x = 0; x < N; x++) lt_child_begin[x + 1] = lt_child_begin[x] + nchild[x];
+    lt_child_cp.assign(edge_node.size(), 0);
+    lt_child_node.assign(edge_node.size(), 0);
+    std::vector<uint32_t> fill(lt_child_begin.begin(), lt_child_begin.end() - 1);
+    for (size_t e = 0; e < edge_node.size(); e++) {  // (creation order: ascending code points under one parent)
+      const uint32_t at = fill[edge_parent[e]]++;
+      lt_child_cp[at] = edge_cp[e];
+      lt_child_node[at] = edge_node[e];
+    }
+    lt_chain_len.assign(N, 0);
+    lt_chain_off.assign(N, 0);
+    for (uint32_t x = N; x-- > 0;) {
+      if (nchild[x] == 1) lt_chain_len[x] = 1 + lt_chain_len[x + 1];  // (the only child of x is x + 1)
+    }
+    for (uint32_t x = 0; x < N; x++) {
+      if (!lt_chain_len[x]) continue;
+      const uint32_t k = creator[x + lt_chain_len[x]];  // the token that runs through the whole chain
+      lt_chain_off[x] = elig_start[k] + depth[x];
+    }
   }
 };
 

@@ -302,11 +302,60 @@ __global__ __launch_bounds__(kBlock) void anchor_gap_kernel(const uint32_t *__re
   if (threadIdx.x == 0 && m > 0) atomicMax(max_gap, static_cast<uint32_t>(m));
 }
 
-// reach[q] = q + length of the token the walk would take at q (q itself: none, or a space)
+// The coverage rule costs a match lookup per text position, and only the stretches the class rule leaves without
+// anchors need it: gaps of more than kMaxAnchorGap positions between two class-rule anchors (a Chinese paragraph
+// without blanks next to English, Russian or Japanese text that the class rule handles fine).  A tile of kReachTile
+// <= kMaxAnchorGap positions meets at most two such gaps — one that holds its first position, one that holds its
+// last — so per tile two numbers say where the coverage rule applies: [tile start, gap_a_end) and [gap_b_start, tile
+// end); everywhere else the class rule stands.  (No match crosses a class-rule anchor — a hard spacing char occurs
+// inside no token — so the cover of a gap starts at its own first position.)  all != 0: the whole text (WP_OPT_COVER_ANCHORS).
+static_assert(kReachTile <= static_cast<int>(kMaxAnchorGap), "a tile meets at most two long gaps");
+__global__ __launch_bounds__(kBlock) void gap_tiles_kernel(const uint32_t *__restrict__ anchors,
+                                                           const uint32_t *__restrict__ n_anchors_dev, size_t n_text,
+                                                           unsigned tiles, int all, uint32_t *__restrict__ gap_a_end,
+                                                           uint32_t *__restrict__ gap_b_start) {
+  const unsigned t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= tiles) return;
+  const uint32_t t0 = t * static_cast<uint32_t>(kReachTile);
+  const uint32_t t1 = static_cast<uint32_t>(min(static_cast<size_t>(t0) + kReachTile, n_text));
+  if (all) {
+    gap_a_end[t] = t1;
+    gap_b_start[t] = t0;
+    return;
+  }
+  const uint32_t na = *n_anchors_dev;
+  auto gap_of = [&](uint32_t p, uint32_t &lo, uint32_t &hi) {  // the stretch between two anchors that holds p
+    uint32_t a = 0, b = na;                                    // first anchor > p
+    while (a < b) {
+      const uint32_t md = (a + b) >> 1;
+      if (anchors[md] <= p) a = md + 1; else b = md;
+    }
+    lo = a ? anchors[a - 1] : 0u;
+    hi = a < na ? anchors[a] : static_cast<uint32_t>(n_text);
+  };
+  uint32_t lo, hi;
+  gap_of(t0, lo, hi);
+  gap_a_end[t] = hi - lo > kMaxAnchorGap ? min(hi, t1) : t0;
+  gap_of(t1 - 1, lo, hi);
+  gap_b_start[t] = hi - lo > kMaxAnchorGap ? max(lo, t0) : t1;
+}
+
+// reach[q] = q + length of the token the walk would take at q (q itself: none, or a space); tiles the coverage
+// rule does not apply to are skipped
 __global__ __launch_bounds__(kBlock) void reach_kernel(WalkArgs a, uint32_t *__restrict__ reach,
-                                                       uint32_t *__restrict__ tile_max) {
+                                                       uint32_t *__restrict__ tile_max,
+                                                       const uint32_t *__restrict__ gap_a_end,
+                                                       const uint32_t *__restrict__ gap_b_start) {
   __shared__ int32_t sm[8];
   const size_t base = static_cast<size_t>(blockIdx.x) * kReachTile;
+  {
+    const uint32_t t0 = static_cast<uint32_t>(base);
+    const uint32_t t1 = static_cast<uint32_t>(min(base + kReachTile, a.n_text));
+    if (gap_a_end[blockIdx.x] <= t0 && gap_b_start[blockIdx.x] >= t1) {  // (uniform)
+      if (threadIdx.x == 0) tile_max[blockIdx.x] = 0u;
+      return;
+    }
+  }
   uint32_t mx = 0;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
@@ -349,22 +398,28 @@ __global__ __launch_bounds__(1024) void reach_spine_kernel(uint32_t *__restrict_
   }
 }
 
-// aflags[p] = 1 iff p is a non-space word-prefix position that no earlier match reaches across
+// aflags[p] = 1 iff p is a non-space word-prefix position that no earlier match reaches across (inside the long
+// gaps, gap_tiles_kernel), or a class-rule anchor (everywhere else)
 __global__ __launch_bounds__(kBlock) void cover_flags_kernel(const uint8_t *__restrict__ cls,
                                                              const uint32_t *__restrict__ reach,
                                                              const uint32_t *__restrict__ tile_before, size_t n,
                                                              uint8_t *__restrict__ aflags,
                                                              uint32_t *__restrict__ tile_first_wp,
-                                                             uint32_t *__restrict__ tile_first_ns) {
+                                                             uint32_t *__restrict__ tile_first_ns,
+                                                             const uint32_t *__restrict__ gap_a_end,
+                                                             const uint32_t *__restrict__ gap_b_start) {
   __shared__ int32_t wm[4];
   __shared__ int32_t sm_min[8];
   int32_t first_wp = 0x7fffffff, first_ns = 0x7fffffff;  // first word-prefix / non-space position of this thread
   const int lane = lane_id(), w = wave_id();
   const size_t p0 = static_cast<size_t>(blockIdx.x) * kReachTile + static_cast<size_t>(threadIdx.x) * 8;
+  const uint32_t ga = gap_a_end[blockIdx.x], gb = gap_b_start[blockIdx.x];
+  const uint32_t tile0 = blockIdx.x * static_cast<uint32_t>(kReachTile);
+  const bool any_cover = ga > tile0 || static_cast<size_t>(gb) < min(static_cast<size_t>(tile0) + kReachTile, n);  // (uniform)
   int32_t r[8], mx = 0;
 #pragma unroll
   for (int j = 0; j < 8; j++) {
-    r[j] = p0 + j < n ? static_cast<int32_t>(reach[p0 + j]) : 0;
+    r[j] = (any_cover && p0 + j < n) ? static_cast<int32_t>(reach[p0 + j]) : 0;
     mx = max(mx, r[j]);
   }
   const int32_t inc = wave_incl_max(mx);
@@ -379,8 +434,11 @@ __global__ __launch_bounds__(kBlock) void cover_flags_kernel(const uint8_t *__re
     const size_t p = p0 + j;
     if (p < n) {
       const uint8_t c = cls[p];
-      const bool wp = p == 0 || (c & kClsSpacing) || (cls[p - 1] & kClsSpacing);
-      aflags[p] = (!(c & kClsSpace) && wp && cover <= static_cast<int32_t>(p)) ? 1 : 0;
+      const uint8_t cp = p ? cls[p - 1] : 0;
+      const bool wp = p == 0 || (c & kClsSpacing) || (cp & kClsSpacing);
+      const bool covered_rule = p < ga || p >= gb;
+      const bool anchor = covered_rule ? (wp && cover <= static_cast<int32_t>(p)) : (p == 0 || w_hard(c) || w_hard(cp));
+      aflags[p] = (!(c & kClsSpace) && anchor) ? 1 : 0;
       cover = max(cover, r[j]);
       if (wp) first_wp = min(first_wp, static_cast<int32_t>(p));
       if (!(c & kClsSpace)) first_ns = min(first_ns, static_cast<int32_t>(p));
@@ -551,6 +609,130 @@ __global__ __launch_bounds__(kBlock) void walk_kernel(WalkArgs a, const uint32_t
   walk_from(a, start, o);
 }
 
+// ---- wide walk: a whole wave per long word ---------------------------------------------------------------------
+// A lane takes its word token by token, and a token is a chain of ~5 dependent loads: a 512-character word of
+// one-character pieces (config 5: 200 tokens per word, every word long) keeps its lane busy for 200 such chains,
+// whatever the other lanes do.  Under the class rule with only hard spacing chars a stretch [anchor, next anchor)
+// is one word and the blanks behind it, so a stretch of more than kWideMin positions is handed to a whole wave: it
+// looks up the token of EVERY position of the word, 256 positions per round trip (four independent chains per
+// lane), finds the positions the greedy walk stands on by pointer doubling over their successors in LDS
+// (8 steps for 256 positions), and the lanes on the chain write their ids, in order, into the word's own
+// stretch of the scratch array — where the lane walk's list assembly picks them up (count | kWideFlag in
+// wide_cnt[anchor index]).  A position of the chain without a token makes the whole word [UNK] (linear.cpp:257-272).
+constexpr uint32_t kWideMin = 48;
+constexpr uint32_t kWideFlag = 0x80000000u;
+constexpr int kWidePerLane = 4;
+constexpr int kWideWindow = kWave * kWidePerLane;  // positions per round trip
+
+__global__ __launch_bounds__(kBlock) void wide_collect_kernel(const uint32_t *__restrict__ anchors,
+                                                              const uint32_t *__restrict__ n_anchors_dev, size_t n_text,
+                                                              uint32_t *__restrict__ list, uint32_t *__restrict__ count) {
+  const size_t na = *n_anchors_dev;
+  for (size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; k < na;
+       k += static_cast<size_t>(gridDim.x) * kBlock) {
+    const uint32_t lo = anchors[k];
+    const uint32_t hi = k + 1 < na ? anchors[k + 1] : static_cast<uint32_t>(n_text);
+    if (hi - lo > kWideMin) list[atomicAdd(count, 1u)] = static_cast<uint32_t>(k);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void walk_wide_kernel(WalkArgs a, const uint32_t *__restrict__ anchors,
+                                                           const uint32_t *__restrict__ n_anchors_dev,
+                                                           const uint32_t *__restrict__ list,
+                                                           const uint32_t *__restrict__ count,
+                                                           uint32_t *__restrict__ wide_cnt) {
+  constexpr int WAVES = kBlock / kWave;
+  constexpr uint32_t kEnd = 0xffffu;  // successor of a position behind the word's end
+  __shared__ uint16_t s_jump_mem[WAVES][2][kWideWindow];
+  __shared__ uint8_t s_mark_mem[WAVES][kWideWindow];
+  // (volatile: the lanes of a wave talk through these arrays — a value another lane wrote must not be served from a register)
+  volatile uint16_t (*s_jump)[2][kWideWindow] = s_jump_mem;
+  volatile uint8_t (*s_mark)[kWideWindow] = s_mark_mem;
+  const int lane = lane_id(), wv = wave_id();
+  const size_t na = *n_anchors_dev;
+  const uint32_t n_wide = *count;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  for (size_t wi = static_cast<size_t>(blockIdx.x) * WAVES + wv; wi < n_wide; wi += static_cast<size_t>(gridDim.x) * WAVES) {
+    const uint32_t k = list[wi];
+    const uint32_t start = anchors[k];
+    const uint32_t next = static_cast<size_t>(k) + 1 < na ? anchors[k + 1] : static_cast<uint32_t>(a.n_text);
+    uint32_t e = next;  // the word ends at the first space of the stretch
+    for (uint32_t base = start; base < next; base += kWave) {
+      const uint32_t q = base + lane;
+      const uint64_t m = __ballot(q < next && (a.cls[q] & kClsSpace));
+      if (m) {
+        e = base + static_cast<uint32_t>(__ffsll(static_cast<long long>(m)) - 1);
+        break;
+      }
+    }
+    int32_t *out = a.emit + start;
+    uint32_t c = 0;
+    bool failed = false;
+    uint32_t pos = start;
+    while (pos < e && !failed) {
+      int32_t id[kWidePerLane];
+      uint32_t jp[kWidePerLane];
+#pragma unroll
+      for (int j = 0; j < kWidePerLane; j++) {  // (four independent chains of loads in flight)
+        const uint32_t i = static_cast<uint32_t>(j) * kWave + lane;
+        const uint32_t q = pos + i;
+        id[j] = -1;
+        jp[j] = kEnd;
+        if (q < e) {
+          const int st = step_lookup(a.steps, rank_of(a.rank[q]));
+          const int32_t raw = w_word_prefix(a, q) ? a.steps.pval_prefix[st] : a.steps.pval_suffix[st];
+          int32_t t = step_id(a.steps, raw);
+          if (!wp_in_bounds(t >= -1 && t < a.n_tokens, kSiteTokenId)) t = -1;
+          id[j] = t;
+          jp[j] = t == -1 ? i : i + static_cast<uint32_t>(step_len(a.steps, raw, a.tok_len));  // (no token: a terminal of its own)
+        }
+      }
+      int cur = 0;
+#pragma unroll
+      for (int j = 0; j < kWidePerLane; j++) {
+        const uint32_t i = static_cast<uint32_t>(j) * kWave + lane;
+        s_jump[wv][0][i] = static_cast<uint16_t>(min(jp[j], kEnd));
+        s_mark[wv][i] = i == 0 ? 1 : 0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int span = 1; span < kWideWindow; span *= 2) {  // after r steps: the chain's first 2^r positions are marked
+        uint16_t nj[kWidePerLane];
+#pragma unroll
+        for (int j = 0; j < kWidePerLane; j++) {
+          const uint32_t i = static_cast<uint32_t>(j) * kWave + lane;
+          const uint32_t t = s_jump[wv][cur][i];
+          if (s_mark[wv][i] && t < static_cast<uint32_t>(kWideWindow)) s_mark[wv][t] = 1;
+          nj[j] = t < static_cast<uint32_t>(kWideWindow) ? s_jump[wv][cur][t] : static_cast<uint16_t>(t);
+        }
+#pragma unroll
+        for (int j = 0; j < kWidePerLane; j++) s_jump[wv][cur ^ 1][static_cast<uint32_t>(j) * kWave + lane] = nj[j];
+        cur ^= 1;
+        __builtin_amdgcn_wave_barrier();
+      }
+      // where the chain leaves the window (>= kWideWindow), ends (kEnd) or breaks (a position < kWideWindow)
+      const uint32_t land = s_jump[wv][cur][0];
+      failed = land < static_cast<uint32_t>(kWideWindow);
+      if (!failed) {
+#pragma unroll
+        for (int j = 0; j < kWidePerLane; j++) {
+          const uint32_t i = static_cast<uint32_t>(j) * kWave + lane;
+          const bool on = s_mark[wv][i] != 0 && id[j] >= 0;
+          const uint64_t m = __ballot(on);
+          if (on) out[c + static_cast<uint32_t>(__popcll(m & lt))] = id[j];
+          c += static_cast<uint32_t>(__popcll(m));
+        }
+        pos = land == kEnd ? e : pos + land;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (failed) {  // the one [UNK] of the word
+      if (lane == 0) out[0] = a.unk_id;
+      c = 1;
+    }
+    if (lane == 0) wide_cnt[k] = c | kWideFlag;
+  }
+}
+
 // A lane per word makes every wave wait for its longest word: 1.2 tokens per word on average, 7 in the slowest of
 // 64 lanes, and a token is a chain of ~5 dependent loads (the kernel ran 84 % waiting, 20 us per wave).  Here a
 // wave owns kWbPerWave consecutive words and deals them out as lanes fall idle: every iteration each busy lane
@@ -564,10 +746,13 @@ struct LinearStep {
   __device__ static __forceinline__ bool step(const WalkArgs &a, WalkState &s, StagedOut &o) { return walk_step(a, s, o); }
 };
 
-template <typename Args, typename Step>
+template <typename Args, typename Step, bool WIDE = false>
 __global__ __launch_bounds__(kBlock) void walk_balanced_kernel(Args a, const uint32_t *__restrict__ anchors,
                                                                const uint32_t *__restrict__ n_anchors_dev, size_t cap,
-                                                               int32_t *__restrict__ ctmp, uint32_t *__restrict__ blk_cnt) {
+                                                               int32_t *__restrict__ ctmp, uint32_t *__restrict__ blk_cnt,
+                                                               const uint32_t *__restrict__ wide_cnt) {
+  // WIDE: stretches of more than kWideMin positions were walked by walk_wide_kernel — their ids sit in
+  // the word's own stretch of a.emit, their count (| kWideFlag) in wide_cnt[anchor index]
   __shared__ int32_t stage[kStageIds * kWbWords];
   __shared__ uint32_t cnt[kWbWords];
   __shared__ uint32_t sm[8];
@@ -582,10 +767,19 @@ __global__ __launch_bounds__(kBlock) void walk_balanced_kernel(Args a, const uin
   bool active = a0 + static_cast<size_t>(widx) < na;
   typename Step::State s{0, 0};
   StagedOut o{stage + widx, a.emit, 0, 0, kWbWords};
+  auto taken_wide = [&](int wd, uint32_t start) {  // true: the word is not this lane's to walk
+    if (!WIDE) return false;
+    const size_t k = a0 + static_cast<size_t>(wd);
+    const uint32_t hi = k + 1 < static_cast<size_t>(*n_anchors_dev) ? anchors[k + 1] : static_cast<uint32_t>(a.n_text);
+    if (hi - start <= kWideMin) return false;
+    cnt[wd] = wide_cnt[k];
+    return true;
+  };
   if (active) {
     const uint32_t start = anchors[a0 + widx];
     s = typename Step::State{start, start};
     o.spill = a.emit + start;
+    if (taken_wide(widx, start)) active = false;
   }
   for (;;) {
     if (active) {
@@ -604,30 +798,32 @@ __global__ __launch_bounds__(kBlock) void walk_balanced_kernel(Args a, const uin
           const uint32_t start = anchors[a0 + widx];
           s = typename Step::State{start, start};
           o = StagedOut{stage + widx, a.emit + start, 0, 0, kWbWords};
-          active = true;
+          active = !taken_wide(widx, start);
         }
       }
       next += __popcll(idle);
     }
-    if (!__ballot(active)) break;
+    // (a lane that was dealt a wide word is idle again at once: the wave is done when nobody walks AND no word is left)
+    if (!__ballot(active) && (!WIDE || next >= kWbPerWave)) break;
   }
   __syncthreads();
   // the lists of the words, one behind the other: thread t appends words kPer * t ...
   constexpr int kPer = kWbWords / kBlock;
   uint32_t mine = 0;
 #pragma unroll
-  for (int q = 0; q < kPer; q++) mine += cnt[threadIdx.x * kPer + q];
+  for (int q = 0; q < kPer; q++) mine += cnt[threadIdx.x * kPer + q] & (WIDE ? ~kWideFlag : ~0u);
   uint32_t tot;
   uint32_t ex = block_excl_sum(mine, sm, tot);
   const size_t base = a0 < na ? anchors[a0] : 0;
 #pragma unroll
   for (int q = 0; q < kPer; q++) {
     const int wq = threadIdx.x * kPer + q;
-    const uint32_t c = cnt[wq];
+    const uint32_t c = cnt[wq] & (WIDE ? ~kWideFlag : ~0u);
+    const uint32_t staged = (WIDE && (cnt[wq] & kWideFlag)) ? 0u : static_cast<uint32_t>(kStageIds);  // (a wide word: everything in its stretch)
     if (c == 0) continue;
-    const int32_t *spill = c > static_cast<uint32_t>(kStageIds) ? a.emit + anchors[a0 + wq] : nullptr;
+    const int32_t *spill = c > staged ? a.emit + anchors[a0 + wq] : nullptr;
     for (uint32_t j = 0; j < c; j++) {
-      ctmp[base + ex + j] = j < static_cast<uint32_t>(kStageIds) ? stage[j * kWbWords + wq] : spill[j];
+      ctmp[base + ex + j] = j < staged ? stage[j * kWbWords + wq] : spill[j];
     }
     ex += c;
   }
