@@ -44,7 +44,9 @@ ROUND_BYTES = 110      # rounds >= 1, per list entry: LDS sort 28 + split 50 + r
 
 # In-container calibration of the CPU port against the compiled reference (filled in from
 # DESIGN.md section 4): same config-2 synthetic, 8 vCPUs of the build container.
-CPU_CALIBRATION = "TBD"
+CPU_CALIBRATION = ("build container (8 vCPU Xeon 2.1 GHz), config-2 synthetic 100 MB, idle: CPU port 43.4 s on 8 threads / 42.1 s on 1 "
+                   "(24 MB: 2.7 s / 7.0 s); compiled reference per SURVEY 8(c) probe: 17.4 s on 8 vCPU / 62.7 s on 1 pool thread; "
+                   "reference's published laptops: 9.4-18.9 MB/s")
 
 _DevView = W.DeviceIds  # zero-copy torch view of a device buffer owned by the library
 
@@ -399,6 +401,20 @@ def main():
             out["host_to_host"] = {"ms_per_step": round(hw * 1e3, 3), "MB_per_s": round(nbytes / 1e6 / hw, 1),
                                    "h2d_ms": round(h2d / reps, 3), "d2h_ms": round(d2h / reps, 3),
                                    "note": "h2d_ms is host time of the (synchronous, pageable-source) upload; d2h into pinned memory"}
+            # the same through the shard pipeline (wp_linear_encode_batch): a sequence of shards of one corpus, uploads and
+            # id downloads on copy streams beside the neighbouring shard's kernels
+            k = 8
+            got = []
+            vocab_h.encode_stream([text] * 2, lambda i, ids: None)  # (warm: second text buffer, staging buffers, pinned blocks)
+            t1 = time.perf_counter()
+            vocab_h.encode_stream([text] * k, lambda i, ids: got.append((i, len(ids), int(ids[0]) if len(ids) else -1)))
+            bw = (time.perf_counter() - t1) / k
+            bs = vocab_h.stats()
+            same_ids = [g[0] for g in got] == list(range(k)) and all(g[1] == int(n_ids) for g in got)
+            out["host_to_host_stream"] = {"ms_per_shard": round(bw * 1e3, 3), "MB_per_s": round(nbytes / 1e6 / bw, 1), "shards": k,
+                                          "ids_per_shard_as_single_call": same_ids,
+                                          "upload_ms_per_shard": round(bs["ms_h2d"] / k, 3), "device_ms_per_shard": round(bs["ms_total"] / k, 3),
+                                          "note": "wp_linear_encode_stream: %d shards of this size back to back, pageable sources, ids delivered in two pinned blocks taking turns" % k}
             # the sibling fast path (word_piece::fast), device resident
             vocab_h.fast_encode_device(d_text.data_ptr(), nbytes)
             torch.cuda.synchronize()

@@ -87,6 +87,14 @@ int wp_linear_encode_multi(wp_vocab *v, const char *utf8, size_t nbytes, const i
 int wp_linear_encode_batch(wp_vocab *v, const char *const *texts, const size_t *nbytes, size_t n_texts,
                            int32_t **ids, size_t *n_ids);
 
+/* The same pipeline for a corpus of any length, with constant memory: `next` supplies text i (return 0: no more; the
+ * pointer must stay valid until the following call of `next`), `out` receives the ids of text i — in order, one text
+ * behind the encodes, valid during the call only (two pinned blocks take turns).  This is the sustained form of the
+ * host-to-host metric: uploads, kernels and downloads of neighbouring texts overlap. */
+typedef int (*wp_text_source)(void *user, size_t index, const char **utf8, size_t *nbytes);
+typedef void (*wp_ids_sink)(void *user, size_t index, const int32_t *ids, size_t n_ids);
+int wp_linear_encode_stream(wp_vocab *v, wp_text_source next, wp_ids_sink out, void *user);
+
 /* Sizes the handle's device arenas and host staging for inputs of up to `nbytes`, so that the
  * first encode does not pay for the allocations (about 100 bytes of HBM per input symbol). */
 int wp_reserve(wp_vocab *v, size_t nbytes);
@@ -140,9 +148,7 @@ int64_t wp_vocab_token_utf8(const wp_vocab *v, int64_t i, char *buf, size_t cap)
 #define WP_OPT_STAGE_TIMING 4 /* 1: record per-stage device times with HIP events */
 #define WP_OPT_LCP_KASAI 5    /* 1: build LCP with the chunked Kasai kernel (linear.cpp:18-70)
                                  instead of deriving it inside the doubling rounds */
-#define WP_OPT_FUSED_RERANK 6 /* 1: single-pass group split (chained scan across tiles) instead of
-                                 the default count / prefix / apply kernels; same results, slightly
-                                 slower on MI355X ("measured dead ends") */
+/* (option 6, a single-pass form of the group split, was measured slower and removed) */
 #define WP_OPT_COVER_ANCHORS 7 /* 1: always derive the walk's start positions from the matches
                                  (default: only when the class rule leaves gaps > 2048 positions
                                  and some spacing char occurs inside a multi-char token, e.g. CJK
@@ -204,6 +210,9 @@ typedef struct {
                                  store (one more full-size launch of the radix scatter, not in radix_passes) */
   int32_t trie_refine;        /* 1: the needed groups of round 0 were resolved along the token trie (one walk + one segmented
                                  sort) instead of by prefix-doubling rounds (default in the text-only layout) */
+  int64_t arena_bytes;        /* device memory of the handle's two bump arenas after this encode                     */
+  int32_t list_retries;       /* 1: the needed list outgrew the room it was given and the encode ran a second time   */
+  int32_t reserved2;
   int64_t radix_pass_bytes;   /* algorithmic bytes of the counted radix scatter launches: record read (without the index
                                  column where the pass makes it up) + record written + digit byte written */
 } wp_stats;

@@ -202,6 +202,32 @@ def test_arena_guard_zones_intact(corpus):
                 assert np.array_equal(ids, O.Vocab(vc).encode(t))
 
 
+def test_encode_batch_pipeline_equals_single_calls(corpus):
+    """wp_linear_encode_batch: a sequence of texts through one handle with uploads / kernels / downloads of neighbouring
+    texts overlapped (second text buffer, id staging): per text the same ids as a call of its own, in order, for
+    texts of different sizes, empty texts and texts without ids."""
+    _, _, text, vocab, _ = corpus
+    gv = W.Vocab(vocab)
+    ov = O.Vocab(vocab)
+    parts = [text, b"", text[:1000], b"   ", text[5000:900_000], "привет мир ".encode() * 1000, text, text[:1_500_000]]
+    for _ in range(2):  # (second round: buffers are reused)
+        outs = gv.encode_batch(parts)
+        assert len(outs) == len(parts)
+        for t, o in zip(parts, outs):
+            assert np.array_equal(o, ov.encode(t))
+    st = gv.stats()
+    assert st["n_bytes"] == sum(len(p) for p in parts)
+    assert gv.encode_batch([]) == []
+    # the same pipeline with callbacks (wp_linear_encode_stream): ids arrive in order, valid during the callback
+    got = []
+    gv.encode_stream(iter(parts), lambda i, ids: got.append((i, ids.copy())))
+    assert [g[0] for g in got] == list(range(len(parts)))
+    for t, (_, o) in zip(parts, got):
+        assert np.array_equal(o, ov.encode(t))
+    gv.encode_stream([], lambda i, ids: got.append(None))
+    assert len(got) == len(parts)
+
+
 def test_bench_self_launch_two_ranks():
     """`python bench.py --gpus 2` with no launcher around it: two ranks are started by bench.py itself, rank 0's line
     says n_gpus 2 and names the id gather (gloo rehearsal on this one-GPU box: the ranks share the device)."""
@@ -357,11 +383,10 @@ print("DEBUG_BOUNDS_OK")
 
 
 def test_tuning_switches_do_not_change_ids(tmp_path):
-    """The environment switches select other forms of the same stages (README: "Results never depend on them"):
-    rank kernel as a launch of its own, round-1 rank store, one depth cap for all groups, symbol code rebuilt per
-    encode, match-any histograms, per-position id array, plain step values, every tied group refined, the reference's S layout.
-    Each combination in a child process (the switches are read once per process) on inputs that reach the
-    full-size paths (> 2^22 symbols), against the oracle."""
+    """The environment switches that are left are process-wide defaults of tested behaviours and debugging aids
+    (csrc/context.h, EnvOptions): the reference's S layout, the per-position id array, guard zones, no context pool.
+    Each in a child process (they are read once per process) on inputs that reach the full-size paths (> 2^22
+    symbols), against the oracle."""
     script = tmp_path / "switch_run.py"
     script.write_text('''
 import os, sys
@@ -380,9 +405,7 @@ for text, vocab in cases:
         assert np.array_equal(gv.encode(text), exp)
 print("SWITCH_OK")
 ''' % (os.path.dirname(PKG), os.path.dirname(os.path.abspath(__file__))))
-    combos = [{"WP_NO_RANK_FUSION": "1", "WP_NO_STEP_PACK": "1"}, {"WP_RANK_STORE_SCATTER": "1", "WP_HIST_SKEW": "0"},
-              {"WP_GLOBAL_NEED": "1", "WP_NO_CODE_CACHE": "1", "WP_SPARSE_EMIT": "1"},
-              {"WP_NO_PRUNE": "1"}, {"WP_VOCAB_IN_S": "1", "WP_NO_DIGIT_BYTES": "1"}, {"WP_DOUBLING_ROUNDS": "1"}]
+    combos = [{"WP_VOCAB_IN_S": "1"}, {"WP_SPARSE_EMIT": "1"}, {"WP_ARENA_GUARD": "1", "WP_NO_CONTEXT_POOL": "1"}]
     for combo in combos:
         env = dict(os.environ, **combo)
         r = subprocess.run([os.sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)

@@ -35,13 +35,11 @@ def _combine(d, vocab_lens, which):
     return out.astype(np.int32)
 
 
-def check_all_stages(text, vocab, label="", fused=False):
+def check_all_stages(text, vocab, label=""):
     text = text if isinstance(text, bytes) else text.encode("utf8")
     ov = O.Vocab(vocab)
     d = ov.encode_debug(text)
     gv = W.Vocab(vocab)
-    if fused:
-        gv.set_option(W.WP_OPT_FUSED_RERANK, 1)
     gv.set_option(W.WP_OPT_FULL_DEPTH, 1)
     gv.set_option(W.WP_OPT_KEEP_DEBUG, 1)  # keeps the raw code points for debug_fetch(6)
     ids = gv.encode(text)
@@ -156,22 +154,11 @@ def test_duplicate_vocab_lines_force_full_depth():
     assert v.stats()["full_depth"] == 1
 
 
-def test_fused_rerank_all_stages():
-    """WP_OPT_FUSED_RERANK (single-pass group split): every intermediate array equals the oracle's."""
-    text, vocab = synth.english_corpus(1_000_000, seed=33, vocab_size=4000)
-    check_all_stages(text, vocab, "fused 1MB", fused=True)
-    text, vocab = synth.deep_prefix_corpus(300_000, seed=5, word_len=128, n_stems=16, suffix_stems=4, suffix_len=32)
-    check_all_stages(text, vocab, "fused deep", fused=True)
-    check_all_stages(b"", ["a"], "fused empty", fused=True)
-    check_all_stages("ab ab", ["ab", "x", "ab"], "fused dup", fused=True)
-
-
-def test_fused_rerank_deep_prefix_8mb_ids():
-    """Many doubling rounds over a large list: the deferred group-depth stores of the fused split
-    (suffix_array.h) must not be seen by tiles still computing depths."""
+def test_deep_prefix_8mb_ids_both_refinements():
+    """Many doubling rounds over a large list (the reference's layout), and the same ids from one trie walk + one
+    segmented sort (the default layout)."""
     text, vocab = synth.deep_prefix_corpus(8_000_000, seed=14)
     gv = W.Vocab(vocab)
-    gv.set_option(W.WP_OPT_FUSED_RERANK, 1)
     gv.set_option(W.WP_OPT_VOCAB_IN_S, 1)  # (the doubling rounds: the default layout resolves its needed groups along the token trie)
     ids = gv.encode(text)
     assert gv.stats()["rounds"] >= 4
@@ -179,7 +166,6 @@ def test_fused_rerank_deep_prefix_8mb_ids():
     assert np.array_equal(ids, exp)
     # default layout: one trie walk + one segmented sort whatever the depth of the vocabulary
     gv = W.Vocab(vocab)
-    gv.set_option(W.WP_OPT_FUSED_RERANK, 1)
     assert np.array_equal(gv.encode(text), exp)
     st = gv.stats()
     assert st["trie_refine"] == 1 and st["rounds"] == 2 and st["vocab_in_s"] == 0
@@ -545,3 +531,21 @@ def test_staged_and_sparse_id_output_agree():
             assert b.stats()["staged_emit"] == 0, label
         fa, fb = a.fast_encode(text), b.fast_encode(text)
         assert np.array_equal(fa, exp_fast) and np.array_equal(fb, exp_fast), label
+
+
+def test_needed_list_outgrows_its_room_and_the_encode_retries():
+    """The active list of round 0 is sized from a guess (an eighth of the text, or what the handle's last encode needed).
+    A periodic text whose every suffix shares its key with long tokens puts the whole text on the list: the device keeps
+    the list empty, reports the length it wanted, and the encode runs again with room — same ids, list_retries == 1 once."""
+    words = [b"ab" * 40, b"ab" * 33 + b"c", b"ba" * 25]
+    rng = random.Random(77)
+    text = b" ".join(rng.choice(words) for _ in range(60_000))
+    vocab = ["[UNK]"] + ["ab" * k for k in (1, 2, 5, 9, 14, 20, 33, 40)] + ["##" + "ab" * k for k in (1, 3, 7, 12, 21)] + \
+            ["ba" * k for k in (1, 4, 11, 25)] + ["##c", "##b", "##a", "a", "b"]
+    exp = O.Vocab(vocab).encode(text, threads=8)
+    gv = W.Vocab(vocab)
+    ids = gv.encode(text)
+    st = gv.stats()
+    assert np.array_equal(ids, exp)
+    assert st["list_retries"] == 1 and st["needed_after_round0"] > st["n_total"] // 2
+    assert np.array_equal(gv.encode(text), exp) and gv.stats()["list_retries"] == 0  # (the handle remembers)

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WP_LIB") or os.path.join(_HERE, "libwordpiece_amd.so")
 
 WP_OPT_FULL_DEPTH, WP_OPT_DEVICE, WP_OPT_KEEP_DEBUG, WP_OPT_STAGE_TIMING, WP_OPT_LCP_KASAI = 1, 2, 3, 4, 5
-WP_OPT_FUSED_RERANK, WP_OPT_COVER_ANCHORS, WP_OPT_ARENA_GUARD, WP_OPT_DEVICES, WP_OPT_VOCAB_IN_S = 6, 7, 8, 9, 10
+WP_OPT_COVER_ANCHORS, WP_OPT_ARENA_GUARD, WP_OPT_DEVICES, WP_OPT_VOCAB_IN_S = 7, 8, 9, 10
 WP_OPT_SPARSE_EMIT = 11
 
 # every symbol include/wordpiece_amd.h declares (checked by the CPU test-suite)
@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "wp_linear_encode_device", "wp_linear_encode_file", "wp_linear_encode_external", "wp_set_option",
     "wp_get_stats", "wp_linear_debug_fetch", "wp_free", "wp_last_error", "wp_device_count",
     "wp_linear_encode_multi", "wp_reserve", "wp_fast_encode", "wp_fast_encode_device", "wp_fast_encode_file",
-    "wp_fast_encode_external", "wp_vocab_token_utf8", "wp_trim", "wp_linear_encode_batch",
+    "wp_fast_encode_external", "wp_vocab_token_utf8", "wp_trim", "wp_linear_encode_batch", "wp_linear_encode_stream",
 ]
 
 
@@ -52,13 +52,17 @@ class Stats(C.Structure):
                 ("radix_digit_bytes", C.c_int64), ("ms_host_total", C.c_double), ("guard_zones", C.c_int32),
                 ("n_devices", C.c_int32), ("vocab_in_s", C.c_int32), ("reserved0", C.c_int32),
                 ("needed_after_round0", C.c_int64), ("key_bits", C.c_int32), ("staged_emit", C.c_int32),
-                ("rank_in_pass", C.c_int32), ("trie_refine", C.c_int32), ("radix_pass_bytes", C.c_int64)]
+                ("rank_in_pass", C.c_int32), ("trie_refine", C.c_int32), ("arena_bytes", C.c_int64),
+                ("list_retries", C.c_int32), ("reserved2", C.c_int32), ("radix_pass_bytes", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "active_per_round"}
         d["active_per_round"] = [int(x) for x in self.active_per_round[:max(self.rounds, 0)]]
         return d
 
+
+_TEXT_SOURCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
+_IDS_SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.c_size_t)
 
 _lib = None
 
@@ -89,6 +93,7 @@ def lib():
         L.wp_linear_encode_multi.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.POINTER(i32p),
                                              C.POINTER(C.c_size_t)]
         L.wp_reserve.argtypes = [vp, C.c_size_t]
+        L.wp_linear_encode_stream.argtypes = [vp, _TEXT_SOURCE, _IDS_SINK, vp]
         L.wp_linear_encode_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(i32p),
                                              C.POINTER(C.c_size_t)]
         L.wp_trim.argtypes = [vp]
@@ -220,6 +225,30 @@ class Vocab:
         ns = (C.c_size_t * k)()
         _check(lib().wp_linear_encode_batch(self._h, ptrs, sizes, k, ids, ns))
         return [_adopt_ids(C.cast(ids[i], C.POINTER(C.c_int32)), ns[i]) for i in range(k)]
+
+    def encode_stream(self, texts, sink):
+        """A corpus of any length through the shard pipeline with constant memory (wp_linear_encode_stream): `texts` is
+        an iterable of bytes, `sink(index, ids)` receives each text's ids as a numpy view that is valid during the call
+        only."""
+        it = iter(texts)
+        keep = {}
+
+        @_TEXT_SOURCE
+        def next_text(_user, index, out_ptr, out_len):
+            try:
+                b = _bytes(next(it))
+            except StopIteration:
+                return 0
+            keep["text"] = b  # (the one before may go: the library asks for text i + 1 after text i has been uploaded)
+            out_ptr[0] = C.cast(C.c_char_p(b), C.c_void_p).value
+            out_len[0] = len(b)
+            return 1
+
+        @_IDS_SINK
+        def got(_user, index, ids, n):
+            sink(index, np.ctypeslib.as_array(ids, shape=(n,)) if n else np.zeros(0, dtype=np.int32))
+
+        _check(lib().wp_linear_encode_stream(self._h, next_text, got, None))
 
     def reserve(self, nbytes):
         """Pre-sizes the device arenas and host staging for inputs of up to nbytes (wp_reserve)."""

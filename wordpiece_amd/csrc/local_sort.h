@@ -59,18 +59,6 @@ __global__ void large_groups_close_kernel(const uint32_t *__restrict__ counters,
   lg_off[counters[0]] = counters[1];
 }
 
-// tuning aid (WP_GROUP_STATS=1): entries of the active list by group size class
-// (2, 3-4, 5-8, 9-16, 17-32, 33-64, 65-256, 257-2048, >2048)
-__global__ __launch_bounds__(kBlock) void group_stats_kernel(const uint32_t *__restrict__ ghead, uint32_t n_groups,
-                                                             unsigned long long *__restrict__ out) {
-  const size_t g = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (g >= n_groups) return;
-  const uint32_t s = ghead[g + 1] - ghead[g];
-  const int c = s <= 2 ? 0 : s <= 4 ? 1 : s <= 8 ? 2 : s <= 16 ? 3 : s <= 32 ? 4 : s <= 64 ? 5 : s <= 256 ? 6 : s <= 2048 ? 7 : 8;
-  atomicAdd(&out[c], static_cast<unsigned long long>(s));
-  atomicAdd(&out[9 + c], 1ull);
-}
-
 // entries of large groups -> (key, val, list position) in the large list; key = dense large-group
 // number << rbits | second key.  A wave owns kLxSpan consecutive positions of the large list: one
 // search for its first group, then it only moves forward (large groups are long runs).

@@ -242,63 +242,6 @@ __global__ void needed_list_close_kernel(const uint32_t *__restrict__ totals, ui
   ghead[totals[1]] = totals[0];
 }
 
-// wave-wide form of suffix_vs_token: lane j compares symbol j (64 symbols per step)
-template <typename SymT>
-__device__ __forceinline__ int wave_suffix_vs_token(const SymT *__restrict__ sym, size_t n, size_t v,
-                                                    const uint32_t *__restrict__ cps, uint32_t len,
-                                                    const uint32_t *__restrict__ lut_excl, uint32_t my_tok_sym) {
-  const int lane = lane_id();
-  for (uint32_t base = 0; base < len; base += kWave) {
-    const uint32_t j = base + lane;
-    const uint32_t a = (j < len && v + j < n) ? static_cast<uint32_t>(sym[v + j]) : 0u;
-    const uint32_t b = j < len ? (base == 0 ? my_tok_sym : lut_excl[cps[j]] + 1u) : 0u;
-    const uint64_t diff = __ballot(j < len && a != b);
-    if (diff) {
-      const int fl = __ffsll(static_cast<long long>(diff)) - 1;
-      const uint32_t fa = __shfl(a, fl, kWave), fb = __shfl(b, fl, kWave);
-      return fa < fb ? -1 : 1;
-    }
-  }
-  return 0;
-}
-
-// After the rounds: the group [rng_lo, rng_hi) of a long token is sorted by more symbols than the token
-// has; narrow it to the suffixes the token is a prefix of (sa: slot -> text position, kept for the slots
-// of the needed groups).  One wave per token, one symbol per lane and compare step.
-template <typename SymT>
-__global__ __launch_bounds__(kBlock) void long_token_range_kernel(const uint32_t *__restrict__ sa,
-                                                                  const SymT *__restrict__ sym, size_t n,
-                                                                  const uint32_t *__restrict__ vocab_cps,
-                                                                  const uint32_t *__restrict__ tok_start,
-                                                                  const uint32_t *__restrict__ tok_info, int M,
-                                                                  const uint32_t *__restrict__ lut_excl,
-                                                                  uint32_t *__restrict__ rng_lo,
-                                                                  uint32_t *__restrict__ rng_hi,
-                                                                  const uint8_t *__restrict__ rng_long) {
-  const int m = static_cast<int>((static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6);
-  const int lane = lane_id();
-  if (m >= M || !rng_long[m]) return;  // wave-uniform
-  const uint32_t len = tok_info[m] & 0x0fffffffu;
-  const uint32_t *cps = vocab_cps + tok_start[m];
-  const uint32_t my_sym = static_cast<uint32_t>(lane) < len ? lut_excl[cps[lane]] + 1u : 0u;
-  const uint32_t glo = rng_lo[m], ghi = rng_hi[m];
-  uint32_t lo = glo, hi = ghi;
-  while (lo < hi) {  // first slot whose suffix is not before the token's range
-    const uint32_t md = lo + ((hi - lo) >> 1);
-    if (wave_suffix_vs_token(sym, n, sa[md], cps, len, lut_excl, my_sym) < 0) lo = md + 1; else hi = md;
-  }
-  const uint32_t lb = lo;
-  hi = ghi;
-  while (lo < hi) {  // first slot behind it
-    const uint32_t md = lo + ((hi - lo) >> 1);
-    if (wave_suffix_vs_token(sym, n, sa[md], cps, len, lut_excl, my_sym) <= 0) lo = md + 1; else hi = md;
-  }
-  if (lane == 0) {
-    rng_lo[m] = lb;
-    rng_hi[m] = lo;
-  }
-}
-
 // marks of the text-only layout for the step functions of scanline.h: a token stands in front of the
 // first slot of its range and covers [lo, hi) in the left-to-right sense only
 __global__ __launch_bounds__(kBlock) void virtual_marks_kernel(const uint32_t *__restrict__ rng_lo,

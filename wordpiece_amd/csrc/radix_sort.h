@@ -142,9 +142,6 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
   for (int j = 0; j < ITEMS; j++) {
     const size_t i = idx0 + static_cast<size_t>(j) * idx_step;
     const uint32_t d = dg[j];
-#if defined(WP_HIST_NOCOUNT)  // probe only (profiles/tools/hist_probe.hip): loads without counting
-    if (i < n && d == 0x1ffu) sh[w][0] = 1;
-#else
     if (lds_atomics == 2) {  // (kernel argument: wave-uniform)
       if (i < n) atomicAdd(&flat[d * kHistCopies + (lane & (kHistCopies - 1))], 1u);
       continue;
@@ -160,7 +157,6 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const KeyT *__restri
     phi &= static_cast<uint32_t>(valid >> 32);
     const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
     if (below == 0 && i < n) mycnt[d] = mycnt[d] + __popc(plo) + __popc(phi);
-#endif
   }
   __syncthreads();
 #pragma unroll
@@ -291,28 +287,13 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned ntiles) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / 8;
 }
 
-// Where the values of a pass come from.  PlainVals: the value column (nullptr: the identity, made up by the
-// first pass of a sort).  Another source (suffix_array.h, RankVals) computes them from data the pass would
-// otherwise have had written and read back; it may use the two LDS staging arrays (one kBlock * ITEMS words
-// each), which are idle until the ranking is done.
-struct PlainVals {
-  const uint32_t *vin;
-  template <int ITEMS>
-  __device__ __forceinline__ void fill(uint32_t (&val)[ITEMS], size_t wave_base, int lane, size_t n, uint32_t *, uint32_t *) const {
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-      const size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
-      val[r] = i < n ? (vin ? vin[i] : static_cast<uint32_t>(i)) : 0u;  // vin == nullptr: the identity
-    }
-  }
-};
-
 // STABLE = false: the first pass of a sort has no earlier order to keep — equal digits may leave the tile in any
 // order — so a key takes its rank inside the wave from ONE LDS atomic on the wave's digit counter (the old value)
 // instead of the 8-ballot match-any (about 40 VALU instructions per key; DESIGN.md: the ranking is half of a pass).
-template <typename KeyT, int ITEMS, typename VS = PlainVals, bool STABLE = true>
+// vin == nullptr: the values are the element indices (the identity), made up here instead of read.
+template <typename KeyT, int ITEMS, bool STABLE = true>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
-    const KeyT *__restrict__ kin, VS vs, KeyT *__restrict__ kout,
+    const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
     uint32_t *__restrict__ vout, size_t n, int begin_bit, uint32_t mask,
     const uint32_t *__restrict__ goff, uint8_t *__restrict__ dout, int next_bit, uint32_t next_mask, int dig_from_val) {
   // dout != nullptr: also leave the next pass's digit of every key as one byte at its new position,
@@ -350,7 +331,11 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const bool valid = i < n;
     key[r] = valid ? kin[i] : static_cast<KeyT>(~static_cast<KeyT>(0));
   }
-  vs.template fill<ITEMS>(val, wave_base, lane, n, reinterpret_cast<uint32_t *>(skeys), svals);
+#pragma unroll
+  for (int r = 0; r < ITEMS; r++) {
+    const size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
+    val[r] = i < n ? (vin ? vin[i] : static_cast<uint32_t>(i)) : 0u;
+  }
   volatile uint32_t *mycnt = wcnt[w];
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
@@ -493,11 +478,9 @@ struct BitRange {
 // uniform_low_bits: digits below this bit are close to uniformly distributed (histogram by LDS atomics)
 // dg0/dg1 (optional, n + 64 bytes each, pairs with k0/k1): digit bytes — every scatter leaves the next
 // pass's digits there; dg0_ready: dg0 already holds the first pass's digits (written by the key builder)
-// histogram of a digit that is not known to be uniform: 2 = interleaved copies + LDS atomics, 0 = match-any ballots
-inline int hist_skew_mode() {
-  static const int m = getenv("WP_HIST_SKEW") ? atoi(getenv("WP_HIST_SKEW")) : 2;
-  return m;
-}
+// histogram of a digit that is not known to be uniform: LDS atomics into interleaved copies of the counters (mode 2 of
+// radix_hist_kernel; the match-any form, mode 0, serves the small sorts)
+constexpr int kHistSkewMode = 2;
 
 struct DigitBytes {
   uint8_t *dg0 = nullptr, *dg1 = nullptr;
@@ -510,12 +493,11 @@ struct DigitBytes {
   uint8_t *tail_out(int cur) const { return cur ? dg1 : dg0; }
 };
 
-// first_vals != nullptr: the value source of the FIRST pass (full-size configuration only)
-template <typename KeyT, typename FV = PlainVals>
+template <typename KeyT>
 int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, const BitRange *ranges,
                       int nranges, uint32_t *tmp, size_t tmp_words, hipStream_t st, RadixStats *stats,
                       bool identity_vals = false, int uniform_low_bits = 0, DigitBytes db = DigitBytes(),
-                      const FV *first_vals = nullptr, bool input_order_free = false) {
+                      bool input_order_free = false) {
   // input_order_free: nothing depends on the order the input is in (a sort from scratch, NOT one pass of a sort that a
   // caller runs as several calls, like the second partition pass of the rank store): the first pass may rank by atomics
   int cur = 0;
@@ -566,7 +548,7 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
                          dim3(kBlock), 0, st, ki, dgi, n, b, mask, table, chunk_sums, 0);
     } else {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT, RadixCfg<KeyT>::kItems>), dim3(ntiles),
-                         dim3(kBlock), 0, st, ki, dgi, n, b, mask, table, chunk_sums, b < uniform_low_bits ? 1 : hist_skew_mode());
+                         dim3(kBlock), 0, st, ki, dgi, n, b, mask, table, chunk_sums, b < uniform_low_bits ? 1 : kHistSkewMode);
     }
     if (small && kRadixBins == kBlock) {
       hipLaunchKernelGGL(radix_apply_small_kernel, dim3(nchunks), dim3(kRadixBins), 0, st, table, chunk_sums, nchunks, ntiles);
@@ -576,20 +558,15 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
     }
     if (stats) stats->spans.begin(st);
     const bool made_up_index = identity_vals;
-    const PlainVals vsrc{identity_vals ? static_cast<const uint32_t *>(nullptr) : vi};
+    const uint32_t *vsrc = identity_vals ? static_cast<const uint32_t *>(nullptr) : vi;
     if (small) {
-      if (first_vals) throw std::logic_error("radix_sort_ranges: a value source needs the full-size configuration");
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kSmallItems, PlainVals>), dim3(ntiles),
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kSmallItems, true>), dim3(ntiles),
                          dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
-    } else if (first_vals && pi == 0) {
-      if (!input_order_free) throw std::logic_error("radix_sort_ranges: a value source is the first pass of a sort from scratch");
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, FV, false>), dim3(ntiles),
-                         dim3(kBlock), 0, st, ki, *first_vals, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
     } else if (pi == 0 && input_order_free) {  // (no earlier order to keep: ranks by LDS atomics)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, PlainVals, false>), dim3(ntiles),
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, false>), dim3(ntiles),
                          dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
     } else {
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, PlainVals>), dim3(ntiles),
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, true>), dim3(ntiles),
                          dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
     }
     identity_vals = false;
@@ -606,14 +583,13 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
   return cur;
 }
 
-template <typename KeyT, typename FV = PlainVals>
+template <typename KeyT>
 int radix_sort_pairs(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, int begin_bit, int end_bit,
                      uint32_t *tmp, size_t tmp_words, hipStream_t st, RadixStats *stats, bool identity_vals = false,
-                     int uniform_low_bits = 0, DigitBytes db = DigitBytes(), const FV *first_vals = nullptr,
-                     bool input_order_free = false) {
+                     int uniform_low_bits = 0, DigitBytes db = DigitBytes(), bool input_order_free = false) {
   BitRange r{begin_bit, end_bit};
-  return radix_sort_ranges<KeyT, FV>(k0, v0, k1, v1, n, &r, 1, tmp, tmp_words, st, stats, identity_vals,
-                                     uniform_low_bits, db, first_vals, input_order_free);
+  return radix_sort_ranges<KeyT>(k0, v0, k1, v1, n, &r, 1, tmp, tmp_words, st, stats, identity_vals,
+                                 uniform_low_bits, db, input_order_free);
 }
 
 }  // namespace wp

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void scatter_pairs_kernel(const uint32_t *_
 #pragma unroll
   for (int j = 0; j < kSpItems; j++) {
     const size_t k = base + static_cast<size_t>(j) * kBlock;
-    v[j] = k < m ? val[k] : kRankUnchanged;
+    v[j] = k < m ? (val ? val[k] : static_cast<RankEntry>(k)) : kRankUnchanged;  // val == nullptr: the entry's own index
     d[j] = k < m ? dst[k] : 0u;
   }
 #pragma unroll
@@ -455,7 +455,7 @@ __device__ __forceinline__ void rr_second_half(const RrTile &T, const uint64_t *
       hd[k] = changed ? head_slot : kRankUnchanged;
       if (gd) {
         gd[k] = (f && !single) ? nd : kRankUnchanged;
-      } else if (f && !single) {
+      } else if (f && !single && !rule.final_round) {
         gdepth[x] = nd;  // x is the first slot of this (still tied) group
       }
       if (!lcp) {
@@ -741,233 +741,6 @@ __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restr
       }
       prev_last = __shfl(me[t][kR0Vec - 1], kWave - 1, kWave);
     }
-  }
-}
-
-// ---- round 0 inside the rank store's first partition pass -------------------------------------------------
-// The first partition pass of the rank store reads (position, rank) in suffix order; the rank is the first slot of
-// the suffix's group, which the pass can see for itself in the sorted keys (4 bytes per entry, what reading the
-// rank would have cost).  As the value source of that radix scatter, round0_rank_kernel<false> disappears: no rank
-// array written and read back (0.8 GB per 1e8 suffixes), one full-size launch less.  Same logic as the kernel
-// above in the scatter's layout (a wave takes ITEMS rounds of 64 consecutive entries): group heads by ballots, the
-// head carried in from the entries in front of the wave by the same look-back, and the heads of tied groups
-// listed in the (still idle) LDS staging arrays and walked densely for the depth of their keys.
-struct RankVals {
-  const Key0 *sk;            // the sorted keys
-  const uint8_t *first_len;  // decode table of the symbol code (global: 8 KB, L1-resident)
-  int uniform_bits;
-  uint32_t *gdepth;
-  template <int ITEMS>
-  __device__ __forceinline__ void fill(uint32_t (&val)[ITEMS], size_t wave_base, int lane, size_t n, uint32_t *sa, uint32_t *sb) const {
-    const Key0 *__restrict__ keys = sk;
-    Key0 k[ITEMS];
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-      const size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
-      k[r] = i < n ? keys[i] : static_cast<Key0>(0);
-    }
-    if (wave_base >= n) {  // (wave-uniform: only in the last tile)
-#pragma unroll
-      for (int r = 0; r < ITEMS; r++) val[r] = 0u;
-      return;
-    }
-    const bool have_front = wave_base >= 1 + static_cast<size_t>(lane);
-    const Key0 front = have_front ? keys[wave_base - 1 - lane] : static_cast<Key0>(0);
-    const size_t after_idx = wave_base + static_cast<size_t>(ITEMS) * kWave;
-    const Key0 after = after_idx < n ? keys[after_idx] : static_cast<Key0>(0);
-    size_t carry = wave_base;
-    {
-      const Key0 me0 = __shfl(k[0], 0, kWave);
-      const uint64_t neq = ~__ballot(have_front && front == me0);
-      if (neq & 1ull) {
-        carry = wave_base;
-      } else if (neq) {
-        carry = wave_base - static_cast<size_t>(__ffsll(static_cast<long long>(neq)) - 1);
-      } else {  // (see round0_rank_kernel)
-        size_t hi = wave_base - kWave, lo = 0;
-        const size_t back = static_cast<size_t>(kWave) << (lane < 40 ? lane : 40);
-        const bool valid = lane < 40 && hi >= back;
-        const bool eq = valid && keys[hi - back] == me0;
-        const uint64_t nm = ~__ballot(eq);
-        const int t = __ffsll(static_cast<long long>(nm)) - 1;
-        const size_t back_t = static_cast<size_t>(kWave) << t, back_in = t ? static_cast<size_t>(kWave) << (t - 1) : 0;
-        lo = hi >= back_t ? hi - back_t + 1 : 0;
-        hi -= back_in;
-        carry = wave_key_lower_bound(keys, lo, hi, static_cast<uint64_t>(me0));
-      }
-    }
-    const int w = wave_id();
-    volatile uint32_t *hpos = sa + static_cast<size_t>(w) * (ITEMS * kWave);
-    volatile Key0 *hkey = reinterpret_cast<Key0 *>(sb) + static_cast<size_t>(w) * (ITEMS * kWave);
-    static_assert(sizeof(Key0) <= sizeof(uint32_t), "the tied-head list lives in the 32-bit value staging array");
-    uint32_t listed = 0;  // (wave-uniform)
-    const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
-    Key0 prev_last = __shfl(front, 0, kWave);
-    // (slots fit 32 bits: n <= 2e9)
-    const uint32_t wb32 = static_cast<uint32_t>(wave_base), n32 = static_cast<uint32_t>(n);
-    uint32_t carry32 = static_cast<uint32_t>(carry);
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-      const uint32_t round_base = wb32 + static_cast<uint32_t>(r) * kWave;
-      const uint32_t i = round_base + static_cast<uint32_t>(lane);
-      const Key0 up = __shfl_up(k[r], 1, kWave), dn = __shfl_down(k[r], 1, kWave);
-      const Key0 next_first = r + 1 < ITEMS ? __shfl(k[r + 1 < ITEMS ? r + 1 : r], 0, kWave) : after;
-      const Key0 prevk = lane == 0 ? prev_last : up;
-      const Key0 nextk = lane == kWave - 1 ? next_first : dn;
-      const bool valid = i < n32;
-      const bool f = valid && (i == 0 || prevk != k[r]);
-      const uint64_t bh = __ballot(f);
-      const uint64_t mine = bh & le;
-      const uint32_t head = mine ? round_base + static_cast<uint32_t>(63 - __clzll(static_cast<long long>(mine))) : carry32;
-      val[r] = valid ? head : 0u;
-      const bool tied = f && i + 1 < n32 && nextk == k[r];  // head of a tied group: its depth is wanted
-      const uint64_t bt = __ballot(tied);
-      if (tied) {
-        const uint32_t o = listed + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(bt >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bt), 0u));
-        hpos[o] = i;
-        hkey[o] = k[r];
-      }
-      listed += static_cast<uint32_t>(__popcll(bt));
-      if (bh) carry32 = round_base + static_cast<uint32_t>(63 - __clzll(static_cast<long long>(bh)));
-      prev_last = __shfl(k[r], kWave - 1, kWave);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t q = lane; q < listed; q += kWave) {
-      gdepth[hpos[q]] = static_cast<uint32_t>(count_key_symbols(static_cast<uint64_t>(hkey[q]), kKeyBits, first_len, uniform_bits));
-    }
-  }
-};
-
-// ---- single-pass form: the two passes fused with a chained scan ----------------------------------
-// The split of a round needs, per tile of the list, the exclusive prefix of three scalars (entries
-// that stay active, their group heads, position of the last group head).  Here every workgroup takes
-// a tile ticket (so all lower tiles are running or done), publishes its three scalars as an
-// AGGREGATE, looks back over its predecessors 64 tiles per step (one wave, one predecessor per
-// lane) until it meets an INCLUSIVE prefix, publishes its own INCLUSIVE prefix and carries on with
-// the second half — no separate counting pass over the keys, no tdep round trip.
-// A tile's state is two 64-bit words written/read with relaxed agent-scope atomics (flag and value
-// in one word); a reader only accepts a tile whose two words carry the same flag.
-// Rounds >= 1: tiles still in their first half read the OLD group depths through gdepth_in, so the
-// new depth of a group head is parked in gd[] and stored by gdepth_store_kernel after this launch.
-constexpr uint64_t kLbAgg = 1ull << 62, kLbIncl = 2ull << 62, kLbFlagMask = 3ull << 62;
-
-struct LookbackState {
-  unsigned long long *wa;  // flag | n_active (31 bits) << 31 | n_heads (31 bits)
-  unsigned long long *wb;  // flag | last_flag (32 bits)
-  uint32_t *ticket;
-};
-
-template <typename SymT, bool ROUND0>
-__global__ __launch_bounds__(kBlock) void rerank_fused_kernel(
-    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ slots,
-    const uint32_t *__restrict__ adep, size_t m, unsigned tiles, LookbackState lb, const SymT *__restrict__ sym,
-    const RankEntry *__restrict__ rd, const uint32_t *__restrict__ gdepth_in, size_t n,
-    const uint8_t *__restrict__ first_len, int uniform_bits, DepthRule rule, uint32_t *__restrict__ sa,
-    RankEntry *__restrict__ hd, int32_t *__restrict__ lcp, uint32_t *__restrict__ nslots,
-    uint32_t *__restrict__ nvals, uint32_t *__restrict__ ngid, uint32_t *__restrict__ ndep,
-    uint32_t *__restrict__ ghead, uint32_t *__restrict__ gdepth, uint32_t *__restrict__ gd,
-    uint32_t *__restrict__ totals) {
-  __shared__ uint32_t s_na[4], s_nh[4], s_last[4];
-  __shared__ uint32_t s_tile, s_pre[3];
-  __shared__ uint8_t s_fl[kDecodeTableBytes];
-  if (ROUND0 && uniform_bits <= 0) {
-    for (int q = threadIdx.x; q < kDecodeTableBytes / 4; q += kBlock) {
-      reinterpret_cast<uint32_t *>(s_fl)[q] = reinterpret_cast<const uint32_t *>(first_len)[q];
-    }
-  }
-  if (threadIdx.x == 0) s_tile = atomicAdd(lb.ticket, 1u);
-  __syncthreads();
-  const unsigned tile = s_tile;
-  const int lane = lane_id(), w = wave_id();
-  const size_t wave_base = static_cast<size_t>(tile) * kRrTile + static_cast<size_t>(w) * kRrWaveSpan;
-  RrTile T;
-  rr_first_half<ROUND0, true>(T, keys, m, wave_base, nullptr, vals, adep, rd, gdepth_in, n, s_fl, uniform_bits, rule);
-  if (lane == 0) {
-    s_na[w] = T.na;
-    s_nh[w] = T.nh;
-    s_last[w] = T.last;
-  }
-  __syncthreads();
-
-  // ---- chained scan (wave 0): publish AGGREGATE, look back, publish INCLUSIVE
-  if (w == 0) {
-    const uint32_t ta = s_na[0] + s_na[1] + s_na[2] + s_na[3];
-    const uint32_t th = s_nh[0] + s_nh[1] + s_nh[2] + s_nh[3];
-    const uint32_t tl = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-    if (lane == 0 && tile > 0) {
-      __hip_atomic_store(&lb.wa[tile], kLbAgg | (static_cast<uint64_t>(ta) << 31) | th, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&lb.wb[tile], kLbAgg | tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    uint64_t ea = 0, eh = 0;
-    uint32_t em = 0;
-    long long t = static_cast<long long>(tile) - 1;
-    while (t >= 0) {
-      const long long mine = t - lane;
-      uint64_t va = 0, vb = 0;
-      bool ok = true;  // lanes past tile 0 count as ready and contribute nothing
-      if (mine >= 0) {
-        va = __hip_atomic_load(&lb.wa[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        vb = __hip_atomic_load(&lb.wb[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = (va & kLbFlagMask) != 0 && (va & kLbFlagMask) == (vb & kLbFlagMask);
-      }
-      const bool incl = mine >= 0 && ok && (va & kLbFlagMask) == kLbIncl;
-      const uint64_t bincl = __ballot(incl);
-      // lanes needed: all up to (and including) the nearest INCLUSIVE one, else the whole window
-      const int upto = bincl ? __ffsll(static_cast<long long>(bincl)) - 1 : kWave - 1;
-      const uint64_t need = upto == 63 ? ~0ull : ((1ull << (upto + 1)) - 1ull);
-      const uint64_t bok = __ballot(ok);
-      if ((bok & need) != need) {  // some needed predecessor has not published yet
-        __builtin_amdgcn_s_sleep(2);
-        continue;
-      }
-      const bool use = lane <= upto && mine >= 0;
-      uint64_t ca = use ? ((va >> 31) & 0x7fffffffull) : 0ull, ch = use ? (va & 0x7fffffffull) : 0ull;
-      uint32_t cm = use ? static_cast<uint32_t>(vb) : 0u;
-#pragma unroll
-      for (int d = kWave / 2; d > 0; d >>= 1) {
-        ca += __shfl_xor(ca, d, kWave);
-        ch += __shfl_xor(ch, d, kWave);
-        cm = max(cm, static_cast<uint32_t>(__shfl_xor(cm, d, kWave)));
-      }
-      ea += ca;
-      eh += ch;
-      em = max(em, cm);
-      if (bincl) break;
-      t -= kWave;
-    }
-    if (lane == 0) {
-      __hip_atomic_store(&lb.wa[tile], kLbIncl | ((ea + ta) << 31) | (eh + th), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&lb.wb[tile], kLbIncl | max(em, tl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_pre[0] = static_cast<uint32_t>(ea);
-      s_pre[1] = static_cast<uint32_t>(eh);
-      s_pre[2] = em;
-      if (tile + 1 == tiles) {  // the last tile knows the totals of the round
-        totals[0] = static_cast<uint32_t>(ea + ta);
-        totals[1] = static_cast<uint32_t>(eh + th);
-        ghead[eh + th] = static_cast<uint32_t>(ea + ta);  // sentinel of the next list's group table
-      }
-    }
-  }
-  __syncthreads();
-  uint32_t ea = s_pre[0], eh = s_pre[1], head1 = s_pre[2];  // head1: 1-based list index
-  for (int i = 0; i < w; i++) {
-    ea += s_na[i];
-    eh += s_nh[i];
-    head1 = max(head1, s_last[i]);
-  }
-  rr_second_half<SymT, ROUND0>(T, keys, m, wave_base, ea, eh, head1, vals, slots, adep, sym, n, s_fl, uniform_bits, sa,
-                               hd, lcp, nslots, nvals, ngid, ndep, ghead, gdepth, ROUND0 ? nullptr : gd, rule);
-}
-
-__global__ __launch_bounds__(kBlock) void gdepth_store_kernel(const uint32_t *__restrict__ gd,
-                                                              const uint32_t *__restrict__ slots, size_t m,
-                                                              uint32_t *__restrict__ gdepth) {
-  const size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (k < m) {
-    const uint32_t v = gd[k];
-    if (v != kRankUnchanged) gdepth[slots[k]] = v;
   }
 }
 
