@@ -371,7 +371,8 @@ def main():
         # (every byte written once is read once; the first pass's bytes come from the key builder: written + read),
         # or the keys the histograms re-read where there are no digit bytes
         pass_bytes = radix_bytes / steps + (17 * n_sym if st["rank_in_pass"] else 0)
-        dig_read = (digit_bytes / steps + (n_sym if st["rank_in_pass"] else 0) + 2 * n_sym) if digit_bytes else key_bytes * radix_elems / steps
+        # (the key builder's digit bytes — written + read — unless it took the first histogram itself)
+        dig_read = (digit_bytes / steps + (n_sym if st["rank_in_pass"] else 0) + (0 if st["hist_in_keys"] else 2 * n_sym)) if digit_bytes else key_bytes * radix_elems / steps
         # no rank kernel of its own where the first partition pass computes the ranks (rank_in_pass) or where a suffix's
         # slot is its rank (trie_refine: nothing asks for group heads)
         split = 0 if (st["rank_in_pass"] or st["trie_refine"]) else SPLIT_BYTES - (4 if st["vocab_in_s"] == 0 else 0)

@@ -212,7 +212,7 @@ typedef struct {
                                  sort) instead of by prefix-doubling rounds (default in the text-only layout) */
   int64_t arena_bytes;        /* device memory of the handle's two bump arenas after this encode                     */
   int32_t list_retries;       /* 1: the needed list outgrew the room it was given and the encode ran a second time   */
-  int32_t reserved2;
+  int32_t hist_in_keys;       /* 1: the key builder took the histogram of the sort's first pass (no digit bytes for it) */
   int64_t radix_pass_bytes;   /* algorithmic bytes of the counted radix scatter launches: record read (without the index
                                  column where the pass makes it up) + record written + digit byte written */
 } wp_stats;

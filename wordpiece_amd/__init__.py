@@ -53,7 +53,7 @@ class Stats(C.Structure):
                 ("n_devices", C.c_int32), ("vocab_in_s", C.c_int32), ("reserved0", C.c_int32),
                 ("needed_after_round0", C.c_int64), ("key_bits", C.c_int32), ("staged_emit", C.c_int32),
                 ("rank_in_pass", C.c_int32), ("trie_refine", C.c_int32), ("arena_bytes", C.c_int64),
-                ("list_retries", C.c_int32), ("reserved2", C.c_int32), ("radix_pass_bytes", C.c_int64)]
+                ("list_retries", C.c_int32), ("hist_in_keys", C.c_int32), ("radix_pass_bytes", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "active_per_round"}

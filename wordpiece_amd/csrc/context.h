@@ -143,7 +143,7 @@ struct Context {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // side stream: latency-bound helpers overlap the bandwidth-bound kernels
-  hipEvent_t evs[3] = {};         // fork / join / scalars fetched
+  hipEvent_t evs[5] = {};         // fork / join / scalars fetched / side stream done with the sorted keys / partition passes queued
   // vocab tables on the device
   uint32_t *d_stream = nullptr, *d_elig_start = nullptr, *d_elig_info = nullptr, *d_soft = nullptr;
   uint32_t *d_vocab_word_idx = nullptr, *d_vocab_word_bits = nullptr;  // the vocabulary's words of the alphabet bitmap

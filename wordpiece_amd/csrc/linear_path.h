@@ -81,7 +81,8 @@ struct LinearPath {
   RerankAgg *d_agg = nullptr, *d_chunk_agg = nullptr;
   // vocabulary-sized
   uint32_t *d_claim = nullptr, *d_claim_need = nullptr, *d_gclaim = nullptr, *d_gfirst = nullptr, *d_gdep = nullptr, *d_gnode = nullptr,
-           *d_gdone = nullptr, *d_rng_lo = nullptr, *d_rng_hi = nullptr, *d_child_sym = nullptr, *d_radix_tmp = nullptr;
+           *d_gdone = nullptr, *d_rng_lo = nullptr, *d_rng_hi = nullptr, *d_child_sym = nullptr, *d_radix_tmp = nullptr,
+           *d_radix_tmp2 = nullptr;  // (second: the large-group sort of the trie round runs on the side stream beside the rank store)
   uint8_t *d_rng_long = nullptr;
   uint32_t *d_mslot0 = nullptr, *d_mslot1 = nullptr, *d_midx0 = nullptr, *d_midx1 = nullptr, *d_minfo = nullptr, *d_tile_mlo = nullptr;
   int32_t *d_mid = nullptr, *d_rf = nullptr, *d_rb = nullptr, *d_cover_f = nullptr, *d_cover_b = nullptr;
@@ -92,6 +93,8 @@ struct LinearPath {
   SymbolCode code;
   DevCode dcode{};
   DigitBytes db;
+  RadixPlan sort_plan;        // round-0 sort: set up ahead of it when the key builder takes its first histogram
+  bool hist_in_keys = false;
   int cur = 0, rounds = 1;
   Key0 *keys = nullptr, *other_keys = nullptr;
   uint32_t *vals = nullptr, *other_vals = nullptr, *slots = nullptr, *other_slots = nullptr, *adep = nullptr, *other_dep = nullptr;
@@ -222,6 +225,7 @@ struct LinearPath {
       d_agg = ar.take<RerankAgg>(rr_tiles_l + 1);
       d_chunk_agg = ar.take<RerankAgg>(cdiv(rr_tiles_l, kRrChunk) + 1);
       d_radix_tmp = ar.take<uint32_t>(radix_words);
+      d_radix_tmp2 = use_trie ? ar.take<uint32_t>(radix_tmp_words<uint64_t>(lc)) : nullptr;
       // vocabulary-sized
       d_claim = ar.take<uint32_t>(claim_size);
       d_claim_need = ar.take<uint32_t>(claim_size);
@@ -327,8 +331,13 @@ struct LinearPath {
     int min_len = code.uniform_bits ? code.uniform_bits : 99;
     for (uint8_t l : code.len) min_len = std::min<int>(min_len, l);
     if (sizeof(SymT) == 1 && min_len >= kKeys8MinLen) {
+      if (n > kRadixSmallN) {  // its tiles are the tiles of the round-0 sort: the first digit's histogram comes along
+        sort_plan = radix_plan<Key0>(n, d_radix_tmp, radix_words, st);
+        hist_in_keys = true;
+      }
       hipLaunchKernelGGL(build_keys0_u8_kernel, dim3(cdiv(n, kKeys8Tile)), dim3(kBlock), 0, st,
-                         reinterpret_cast<const uint8_t *>(d_sym), n, dcode, KA, DG0);
+                         reinterpret_cast<const uint8_t *>(d_sym), n, dcode, KA, hist_in_keys ? nullptr : DG0,
+                         hist_in_keys ? sort_plan.table : nullptr, hist_in_keys ? sort_plan.chunk_sums0 : nullptr);
     } else {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(build_keys0_kernel<SymT>), dim3(cdiv(n, kKeyTile)), dim3(kBlock), 0, st, d_sym, n, dcode,
                          KA, DG0);
@@ -341,7 +350,7 @@ struct LinearPath {
     // (the low bits of a round-0 key are the tail of a compressed codeword stream: near-uniform digits)
     db.dg0 = DG0;
     db.dg1 = DG1;
-    db.dg0_ready = DG0 != nullptr;
+    db.dg0_ready = DG0 != nullptr && !hist_in_keys;
     if (window_store) {  // the last pass leaves the first digit of the rank store's destination partition
       db.tail_bit = kWinBits;
       db.tail_mask = (1u << (win_mid - kWinBits)) - 1u;
@@ -349,7 +358,8 @@ struct LinearPath {
     }
     // histogram: one per-wave LDS counter per digit for the lowest digit (near-uniform), interleaved copies above it
     cur = radix_sort_pairs<Key0>(KA, VA, KB, VB, n, 0, kKeyBits, d_radix_tmp, radix_words, st, &c->rstats, true,
-                                 code.uniform_bits ? 0 : 8, db, true);
+                                 code.uniform_bits ? 0 : 8, db, true, hist_in_keys ? &sort_plan : nullptr);
+    S.hist_in_keys = hist_in_keys ? 1 : 0;
     keys = cur ? KB : KA;
     other_keys = cur ? KA : KB;
     vals = cur ? VB : VA;
@@ -394,7 +404,8 @@ struct LinearPath {
   // pass.  The passes go through the scratch pairs a = (X0, X1) and b = (the value buffer the sort did not end in, the
   // sorted keys — free once the side stream's searches in them are over: before_second).
   // dig: digit bytes of dst bits [kWinBits, ...), left by the last pass of the sort; other: the second byte buffer.
-  void store_ranks_round0(uint32_t *dst, uint32_t *val, uint8_t *dig, uint8_t *other, const std::function<void()> &before_second) {
+  void store_ranks_round0(uint32_t *dst, uint32_t *val, uint8_t *dig, uint8_t *other, const std::function<void()> &before_second,
+                          const std::function<void()> &before_window) {
     // (a per-device attribute: set on every call, the context may live on any device)
     WP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(window_store_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                static_cast<int>(kWinLdsBytes)));
@@ -422,6 +433,7 @@ struct LinearPath {
       f_dst = b_dst;
       f_val = b_val;
     }
+    if (before_window) before_window();
     hipLaunchKernelGGL(window_store_kernel, dim3(cdiv(n, size_t(1) << kWinBits)), dim3(kWinThreads), kWinLdsBytes, st, f_dst, f_val,
                        n, d_rank);
   }
@@ -435,10 +447,11 @@ struct LinearPath {
     // every rank it touches) — so a suffix's own slot serves as its rank and no kernel derives group heads.
     const bool slot_ranks = text_only && !d_lcp;
     uint8_t *dig = DG0 ? db.tail_out(cur) : nullptr, *dig_other = DG0 ? db.tail_out(cur ^ 1) : nullptr;
-    if (prune) {
-      // Depth-capped mode: the groups that have to go on are found from the vocabulary (prune.h) and appended to the
-      // active list by the kernel that finds them — on the side stream (a few thousand waves of searches)
-      fork();
+    // Depth-capped mode: the groups that have to go on are found from the vocabulary (prune.h) and appended to the
+    // active list by the kernel that finds them — on the side stream (a few thousand waves of searches).
+    // start_after != nullptr: the side stream starts there (an event of the main stream).
+    auto enqueue_needed_groups = [&](hipEvent_t start_after) {
+      if (start_after) WP_HIP(hipStreamWaitEvent(st2, start_after, 0));
       WP_HIP(hipMemsetAsync(d_claim, 0xff, claim_size * sizeof(uint32_t), st2));
       WP_HIP(hipMemsetAsync(d_claim_need, 0, claim_size * sizeof(uint32_t), st2));
       NeededList nl{slots, avals, AG, adep, d_ghead, d_gfirst, d_gdep, reinterpret_cast<unsigned long long *>(c->d_scalars + 4),
@@ -465,6 +478,15 @@ struct LinearPath {
                              d_gdep, c->d_scalars + 4, d_sym, n, d_vsym, trie, d_gnode, d_gdone);
         }
       }
+      // (from here on the side stream no longer reads the sorted keys and suffixes: the rank store may reuse them)
+      WP_HIP(hipEventRecord(c->evs[3], st2));
+      if (use_trie) trie_round_sizes();
+    };
+    // (they start when the sort ends, beside the first partition pass's histogram: started beside its scatter instead,
+    // which is bandwidth-bound, they cost the scatter more than they cost the histogram now — measured)
+    if (prune) {
+      fork();
+      enqueue_needed_groups(nullptr);
       if (!slot_ranks) {  // reference layout: rank entries, LCPs and group depths from the sorted keys
         hipLaunchKernelGGL(round0_rank_kernel<true>, dim3(cdiv(n, kR0Tile)), dim3(kBlock), 0, st, keys, vals, n, dcode.first_len,
                            dcode.uniform_bits, d_sa, d_hd_n, d_lcp, d_gdepth);
@@ -484,19 +506,91 @@ struct LinearPath {
                          c->d_scalars + 4);
     }
     uint32_t *rank_vals = slot_ranks ? nullptr : reinterpret_cast<uint32_t *>(d_hd_n);
+    auto keys_free = [&] {  // pair b of the rank store holds the sorted keys: the side stream's searches in them must be over
+      if (prune) WP_HIP(hipStreamWaitEvent(st, c->evs[3], 0));
+    };
+    // The trie round (side stream) starts when the partition passes are through: its small latency-bound kernels run
+    // beside the window store — beside the radix passes they took a quarter of the passes' bandwidth for the same gain.
+    auto start_trie_round = [&] {
+      if (!use_trie) return;
+      WP_HIP(hipEventRecord(c->evs[4], st));
+      WP_HIP(hipStreamWaitEvent(st2, c->evs[4], 0));
+      trie_round_sort();
+    };
     if (window_store) {
-      // (pair b holds the sorted keys: the side stream's searches in them must be over before the second pass)
-      store_ranks_round0(vals, rank_vals, dig, dig_other, [&] {
-        if (prune) join();
-      });
+      store_ranks_round0(vals, rank_vals, dig, dig_other, keys_free, start_trie_round);
     } else {
-      if (prune) join();
+      keys_free();
+      start_trie_round();
       store_ranks(vals, rank_vals, X0, X1, n);
     }
     WP_LAUNCH_CHECK();
-    fork();
-    classified = classify_groups(std::min(n, list_cap));
-    join();
+    if (use_trie) {
+      trie_round_finish();
+    } else {
+      if (prune) join();
+      fork();
+      classified = classify_groups(std::min(n, list_cap));
+      join();
+    }
+  }
+
+  // ---- trie refinement of the needed groups (trie.h), on the side stream BESIDE the window store of the rank store ----
+  // Nothing in it reads a rank: every entry of the needed list walks the token trie (its end node is its sort key),
+  // the groups are sorted by node (LDS windows; large groups through a radix sort with its own temporary), one split
+  // assigns the new slots.  Only the last step — the ranks of the entries that moved — has to wait for the rank table.
+  // The list sizes travel to the host as soon as the list is built, so every launch is queued long before it can run.
+  int trie_rb() const { return bit_length(hv.lt_chain_len.size() + 1); }  // second keys: 1 + trie node
+  void trie_round_sizes() {
+    classified = classify_groups(list_cap);  // (side stream: the table of large groups)
+    WP_HIP(hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(uint32_t) * 12, hipMemcpyDeviceToHost, st2));
+    WP_HIP(hipEventRecord(c->evs[2], st2));
+  }
+  void trie_round_sort() {
+    const TokenTrie trie{c->d_lt_chain_len, c->d_lt_chain_off, c->d_lt_child_begin, c->d_lt_child_node, d_child_sym};
+    // (sizes are read on the device: the launches do not wait for the host to learn them)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(trie_walk_kernel<SymT>), dim3(std::min<size_t>(cdiv(list_cap, kBlock), 16384)), dim3(kBlock), 0,
+                       st2, avals, AG, d_gnode, d_gdone, c->d_scalars + 4, d_sym, n, d_vsym, trie, adep);
+    hipLaunchKernelGGL(local_sort_kernel, dim3(cdiv(list_cap, kLsT)), dim3(kBlock), 0, st2, avals, AG, adep, c->d_scalars + 4,
+                       d_ghead, d_rank, n, trie_rb(), LK0, spare_vals, adep);
+  }
+  void trie_round_finish() {
+    WP_HIP(hipEventSynchronize(c->evs[2]));
+    n_act = c->h_scalars[4];
+    n_large_groups = classified ? c->h_scalars[6] : 0;
+    n_large = classified ? c->h_scalars[7] : 0;
+    if (c->h_scalars[8] > list_cap) throw ListOverflow{c->h_scalars[8]};  // (the list was kept empty: nothing ran on it)
+    S.active_per_round[0] = static_cast<int64_t>(n);
+    uint64_t *skeys = LK0;
+    RankEntry *hd = reinterpret_cast<RankEntry *>(LK1);
+    if (n_act > 0) {
+      S.active_per_round[1] = static_cast<int64_t>(n_act);
+      const int rb = trie_rb();
+      if (n_large > 0) {
+        const int lgb = bit_length(n_large_groups > 0 ? n_large_groups - 1 : 0);
+        hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(cdiv(n_large, kLxSpan), kBlock / kWave)), dim3(kBlock), 0, st2, avals, adep,
+                           d_lg_head, d_lg_off, static_cast<uint32_t>(n_large_groups), n_large, d_rank, n, rb, LK1, LV0, LPOS, adep);
+        const int lc = radix_sort_pairs<uint64_t>(LK1, LV0, LK2, LV1, n_large, 0, rb + lgb, d_radix_tmp2,
+                                                  radix_tmp_words<uint64_t>(list_cap), st2, nullptr);
+        hipLaunchKernelGGL(large_writeback_kernel, dim3(std::min<size_t>(cdiv(n_large, kBlock), 8192)), dim3(kBlock), 0, st2,
+                           lc ? LK2 : LK1, lc ? LV1 : LV0, LPOS, n_large, AG, rb, skeys, spare_vals);
+      }
+      DepthRule rrule{need_depth, 0, nullptr, nullptr, 1, d_node_of_slot};  // final round: every group retires
+      const unsigned tiles = cdiv(n_act, kRrTile);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_agg_kernel<false>), dim3(tiles), dim3(kBlock), 0, st2, skeys, spare_vals, n_act, adep,
+                         d_rank, d_gdepth, n, dcode.first_len, dcode.uniform_bits, rrule, d_tdep, d_agg);
+      hipLaunchKernelGGL(rerank_chunk_kernel, dim3(cdiv(tiles, kRrChunk)), dim3(kBlock), 0, st2, d_agg, tiles, d_chunk_agg);
+      hipLaunchKernelGGL(rerank_prefix_kernel, dim3(cdiv(tiles, kRrChunk)), dim3(kBlock), 0, st2, d_agg, d_chunk_agg, tiles);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rerank_apply_kernel<SymT, false>), dim3(tiles), dim3(kBlock), 0, st2, skeys, spare_vals, slots,
+                         adep, d_tdep, n_act, d_agg, d_sym, n, dcode.first_len, dcode.uniform_bits, rrule, d_sa, hd, d_lcp,
+                         other_slots, avals, AG, other_dep, d_ghead, d_gdepth, c->d_scalars + 4);
+    }
+    join();  // the rank table is complete (main stream) and the new ranks are known (side stream)
+    if (n_act > 0) {
+      store_ranks(spare_vals, hd, reinterpret_cast<uint32_t *>(hd) + list_cap + 2, reinterpret_cast<uint32_t *>(skeys), n_act);
+      rounds = 2;
+    }
+    WP_LAUNCH_CHECK();
   }
 
   // Between two rounds the host needs the new list sizes (grids, large-group path).  The copy of the scalars and the
@@ -505,15 +599,10 @@ struct LinearPath {
   void next_round_begin(size_t upper, int rb) {
     WP_HIP(hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(uint32_t) * 12, hipMemcpyDeviceToHost, st));
     WP_HIP(hipEventRecord(c->evs[2], st));
-    if (upper > 0 && use_trie) {  // every list entry walks the token trie: its end node is its second key (in adep)
-      const TokenTrie trie{c->d_lt_chain_len, c->d_lt_chain_off, c->d_lt_child_begin, c->d_lt_child_node, d_child_sym};
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(trie_walk_kernel<SymT>), dim3(std::min<size_t>(cdiv(upper, kBlock), 16384)), dim3(kBlock), 0, st,
-                         avals, AG, d_gnode, d_gdone, c->d_scalars + 4, d_sym, n, d_vsym, trie, adep);
-    }
     fork();  // the large-group path of the next round (side stream) may start from here
     if (upper > 0) {
       hipLaunchKernelGGL(local_sort_kernel, dim3(cdiv(upper, kLsT)), dim3(kBlock), 0, st, avals, AG, adep, c->d_scalars + 4, d_ghead,
-                         d_rank, n, rb, LK0, spare_vals, use_trie ? adep : static_cast<const uint32_t *>(nullptr));
+                         d_rank, n, rb, LK0, spare_vals, static_cast<const uint32_t *>(nullptr));
     }
     WP_HIP(hipEventSynchronize(c->evs[2]));
     n_act = c->h_scalars[4];
@@ -524,22 +613,32 @@ struct LinearPath {
 
   // ---- rounds >= 1 over the active list --------------------------------------------------------------------------
   // Default layout: ONE split — every entry's second key is the trie node its suffix ends in (trie.h), all groups
-  // retire.  Reference layout / full depth: prefix doubling, a group sorted by rank[i + depth(group)] per round.
+  // retire — run beside the rank store (trie_round_begin / _finish).  Reference layout / full depth: prefix
+  // doubling, a group sorted by rank[i + depth(group)] per round (doubling_rounds).
   void refine() {
-    // second keys of a round: 1 + rank (<= n), or — trie refinement — 1 + trie node
-    const int rb = use_trie ? bit_length(hv.lt_chain_len.size() + 1) : bit_length(n);
+    if (!use_trie) doubling_rounds();  // (trie refinement has run beside the rank store: trie_round_begin / _finish)
+    S.rounds = rounds;
+    // every tie that is left shares at least this many symbols: need_depth for the groups that went through the
+    // rounds, the shortest possible key (whole codewords in kKeyBits bits) for the groups round 0 let go
+    const int max_len = code.uniform_bits ? code.uniform_bits : kMaxCodeLen + code.lo_bits;
+    const int32_t key_syms = std::max(1, kKeyBits / max_len);
+    S.sorted_depth = full ? 0x7fffffff
+                          : (prune ? std::min<int32_t>(static_cast<int32_t>(need_depth), key_syms) : static_cast<int32_t>(need_depth));
+    S.needed_after_round0 = prune ? (rounds > 1 ? S.active_per_round[1] : 0) : -1;
+    if (prune && rounds > 1) c->list_hint = static_cast<size_t>(S.active_per_round[1]);
+  }
+
+  void doubling_rounds() {
+    const int rb = bit_length(n);  // second keys of a round: 1 + rank (<= n)
     const DepthRule rule{need_depth, full ? 1 : 0, nullptr, nullptr, 0, nullptr};
     next_round_begin(std::min(n, list_cap), rb);
     S.active_per_round[0] = static_cast<int64_t>(n);
     // behind a pruned round 0 every group carries the depth its own tokens need (DepthRule, prune.h)
     uint32_t *gneed_cur = d_gneed0, *gneed_nxt = d_gneed1;
-    const bool group_need = prune && M > 0 && !use_trie;
+    const bool group_need = prune && M > 0;
     while (n_act > 0) {
       DepthRule rrule = rule;
-      if (use_trie) {
-        rrule.final_round = 1;
-        rrule.second_out = d_node_of_slot;
-      } else if (group_need) {
+      if (group_need) {
         rrule.gneed_in = gneed_cur;
         rrule.gneed_out = gneed_nxt;
         std::swap(gneed_cur, gneed_nxt);
@@ -561,7 +660,7 @@ struct LinearPath {
         const int lgb = bit_length(n_large_groups > 0 ? n_large_groups - 1 : 0);
         hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(cdiv(n_large, kLxSpan), kBlock / kWave)), dim3(kBlock), 0, st2, avals, adep,
                            d_lg_head, d_lg_off, static_cast<uint32_t>(n_large_groups), n_large, d_rank, n, rb, LK1, LV0, LPOS,
-                           use_trie ? adep : static_cast<const uint32_t *>(nullptr));
+                           static_cast<const uint32_t *>(nullptr));
         const int lc = radix_sort_pairs<uint64_t>(LK1, LV0, LK2, LV1, n_large, 0, rb + lgb, d_radix_tmp, radix_words, st2, nullptr);
         hipLaunchKernelGGL(large_writeback_kernel, dim3(std::min<size_t>(cdiv(n_large, kBlock), 8192)), dim3(kBlock), 0, st2,
                            lc ? LK2 : LK1, lc ? LV1 : LV0, LPOS, n_large, AG, rb, skeys, svals);
@@ -581,10 +680,6 @@ struct LinearPath {
       store_ranks(svals, hd, reinterpret_cast<uint32_t *>(hd) + list_cap + 2, reinterpret_cast<uint32_t *>(skeys), n_act);
       WP_LAUNCH_CHECK();
       rounds++;
-      if (use_trie) {  // (nothing stays on the list)
-        join();
-        break;
-      }
       classified = classify_groups(n_act);
       join();
       std::swap(slots, other_slots);
@@ -593,15 +688,6 @@ struct LinearPath {
       spare_vals = svals;
       next_round_begin(n_act, rb);  // (the next list is at most as long as this one)
     }
-    S.rounds = rounds;
-    // every tie that is left shares at least this many symbols: need_depth for the groups that went through the
-    // rounds, the shortest possible key (whole codewords in kKeyBits bits) for the groups round 0 let go
-    const int max_len = code.uniform_bits ? code.uniform_bits : kMaxCodeLen + code.lo_bits;
-    const int32_t key_syms = std::max(1, kKeyBits / max_len);
-    S.sorted_depth = full ? 0x7fffffff
-                          : (prune ? std::min<int32_t>(static_cast<int32_t>(need_depth), key_syms) : static_cast<int32_t>(need_depth));
-    S.needed_after_round0 = prune ? (rounds > 1 ? S.active_per_round[1] : 0) : -1;
-    if (prune && rounds > 1) c->list_hint = static_cast<size_t>(S.active_per_round[1]);
   }
 
   // ---- who marks + the four scanlines as step functions (linear.cpp:153-213) -----------------------------------------

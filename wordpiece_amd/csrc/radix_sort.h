@@ -493,31 +493,54 @@ struct DigitBytes {
   uint8_t *tail_out(int cur) const { return cur ? dg1 : dg0; }
 };
 
+// Where a sort keeps its offset tables inside `tmp`.  radix_plan() checks the capacity and clears the chunk sums; a
+// caller that already knows the digits of the FIRST pass per tile (the key builder: its tiles are the sort's tiles)
+// fills table / chunk_sums0 itself and hands the plan to the sort, which then skips that histogram launch.
+struct RadixPlan {
+  uint32_t *table = nullptr, *chunk_pre = nullptr, *chunk_sums0 = nullptr;
+  size_t cs_words = 0;
+  unsigned ntiles = 0, nchunks = 0;
+  bool small = false;
+};
+template <typename KeyT>
+RadixPlan radix_plan(size_t n, uint32_t *tmp, size_t tmp_words, hipStream_t st) {
+  RadixPlan p;
+  p.small = n <= kRadixSmallN;
+  p.ntiles = cdiv(n, p.small ? RadixCfg<KeyT>::kSmallTile : RadixCfg<KeyT>::kTile);
+  p.nchunks = cdiv(p.ntiles, kColChunk);
+  const size_t h = static_cast<size_t>(p.ntiles) * kRadixBins;
+  p.cs_words = static_cast<size_t>(p.nchunks + 1) * kRadixBins;
+  if (h + (kMaxZeroedPasses + 1) * p.cs_words > tmp_words) {
+    throw std::logic_error("radix sort: temporary buffer too small (" + std::to_string(tmp_words) + " words for " +
+                           std::to_string(n) + " elements)");
+  }
+  p.table = tmp;
+  p.chunk_pre = tmp + h;
+  p.chunk_sums0 = p.chunk_pre + p.cs_words;
+  // every pass adds into its own chunk-sum table; the first kMaxZeroedPasses are cleared at once
+  WP_HIP(hipMemsetAsync(p.chunk_sums0, 0, sizeof(uint32_t) * p.cs_words * kMaxZeroedPasses, st));
+  return p;
+}
+
+// first_hist: the plan of this sort, made by the caller, with the first pass's histogram already in it
 template <typename KeyT>
 int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, const BitRange *ranges,
                       int nranges, uint32_t *tmp, size_t tmp_words, hipStream_t st, RadixStats *stats,
                       bool identity_vals = false, int uniform_low_bits = 0, DigitBytes db = DigitBytes(),
-                      bool input_order_free = false) {
+                      bool input_order_free = false, const RadixPlan *first_hist = nullptr) {
   // input_order_free: nothing depends on the order the input is in (a sort from scratch, NOT one pass of a sort that a
   // caller runs as several calls, like the second partition pass of the rank store): the first pass may rank by atomics
   int cur = 0;
   if (n == 0) return cur;
-  const bool small = n <= kRadixSmallN;
+  const RadixPlan plan = first_hist ? *first_hist : radix_plan<KeyT>(n, tmp, tmp_words, st);
+  const bool small = plan.small;
   if (small) {
     stats = nullptr;  // the roofline statistics describe the full-size configuration only
     db = DigitBytes();
   }
-  const unsigned ntiles = cdiv(n, small ? RadixCfg<KeyT>::kSmallTile : RadixCfg<KeyT>::kTile);
-  const unsigned nchunks = cdiv(ntiles, kColChunk);
-  const size_t h = static_cast<size_t>(ntiles) * kRadixBins;
-  const size_t cs_words = static_cast<size_t>(nchunks + 1) * kRadixBins;
-  if (h + (kMaxZeroedPasses + 1) * cs_words > tmp_words) {
-    throw std::logic_error("radix_sort_ranges: temporary buffer too small (" + std::to_string(tmp_words) + " words for " +
-                           std::to_string(n) + " elements)");
-  }
-  uint32_t *table = tmp, *chunk_pre = tmp + h, *chunk_sums0 = chunk_pre + cs_words;
-  // every pass adds into its own chunk-sum table; the first kMaxZeroedPasses are cleared at once
-  WP_HIP(hipMemsetAsync(chunk_sums0, 0, sizeof(uint32_t) * cs_words * kMaxZeroedPasses, st));
+  const unsigned ntiles = plan.ntiles, nchunks = plan.nchunks;
+  const size_t cs_words = plan.cs_words;
+  uint32_t *table = plan.table, *chunk_pre = plan.chunk_pre, *chunk_sums0 = plan.chunk_sums0;
   struct Pass {
     int bit;
     uint32_t mask;
@@ -543,7 +566,9 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
     const int nbit = !last ? passes[pi + 1].bit : std::max(db.tail_bit, 0);
     const uint32_t nmask = !last ? passes[pi + 1].mask : db.tail_mask;
     const int from_val = last && db.tail_from_val ? 1 : 0;
-    if (small) {
+    if (first_hist && pi == 0) {
+      // (the caller has taken this histogram)
+    } else if (small) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<KeyT, RadixCfg<KeyT>::kSmallItems>), dim3(ntiles),
                          dim3(kBlock), 0, st, ki, dgi, n, b, mask, table, chunk_sums, 0);
     } else {
@@ -586,10 +611,11 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
 template <typename KeyT>
 int radix_sort_pairs(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, int begin_bit, int end_bit,
                      uint32_t *tmp, size_t tmp_words, hipStream_t st, RadixStats *stats, bool identity_vals = false,
-                     int uniform_low_bits = 0, DigitBytes db = DigitBytes(), bool input_order_free = false) {
+                     int uniform_low_bits = 0, DigitBytes db = DigitBytes(), bool input_order_free = false,
+                     const RadixPlan *first_hist = nullptr) {
   BitRange r{begin_bit, end_bit};
   return radix_sort_ranges<KeyT>(k0, v0, k1, v1, n, &r, 1, tmp, tmp_words, st, stats, identity_vals,
-                                 uniform_low_bits, db, input_order_free);
+                                 uniform_low_bits, db, input_order_free, first_hist);
 }
 
 }  // namespace wp
