@@ -317,11 +317,9 @@ def main():
         steps = max(args.steps, 1)
         key_bytes = 4 if 0 < st["key_bits"] <= 32 else 8
         RADIX_BYTES_PER_ELEM = 2 * (key_bytes + 4)
-        scatter_name = "radix_scatter_kernel<%s, PlainVals> (full-size tiles: the %d passes of the round-0 suffix sort over %d-bit keys%s; %d-byte records)" % (
+        scatter_name = "radix_scatter_kernel<%s, stable|first-pass> (full-size tiles: the %d passes of the round-0 suffix sort over %d-bit keys%s; %d-byte records)" % (
             "uint32, 16" if key_bytes == 4 else "uint64, 24", (st["key_bits"] + 7) // 8, st["key_bits"],
-            (" and the second destination-partition pass of the round-0 rank store (the first one also computes the ranks: "
-             "the RankVals instantiation, another kernel, not counted here)" if st["rank_in_pass"] else
-             " and the destination-partition passes of the round-0 rank store (the first one makes its value column — the slots — up)")
+            " and the two destination-partition passes of the round-0 rank store (the first one makes its value column - the slots - up)"
             if key_bytes == 4 else "", key_bytes + 4)
         ms_per_step = dt_max / args.steps * 1e3
         value = total_bytes / 1e6 / (dt_max / args.steps)
@@ -352,8 +350,9 @@ def main():
                        "sorted_depth": st["sorted_depth"], "symbol_bits": st["symbol_bits"],
                        "symbols_per_key": st["symbols_per_key"], "key_bits": st["key_bits"], "active_per_round": st["active_per_round"],
                        "needed_after_round0": st["needed_after_round0"],
-                       "radix_launches_per_step": radix_launches // steps, "staged_emit": st["staged_emit"], "rank_in_pass": st["rank_in_pass"],
-                       "trie_refine": st["trie_refine"],
+                       "radix_launches_per_step": radix_launches // steps, "staged_emit": st["staged_emit"],
+                       "trie_refine": st["trie_refine"], "hist_in_keys": st["hist_in_keys"], "list_retries": st["list_retries"],
+                       "arena_bytes": st["arena_bytes"], "arena_bytes_per_symbol": round(st["arena_bytes"] / max(st["n_total"], 1), 1),
                        "id_gather": ("%s: exact-size receives on rank 0" % ("rccl" if backend == "nccl" else backend)) if distributed
                        else "none (single GPU)"},
             "roofline": {"bound": "hbm", "kernel": scatter_name, "achieved": round(achieved, 1),
@@ -366,16 +365,13 @@ def main():
         # the whole SA/LCP stage against the HBM peak, SURVEY 8(d) style: algorithmic bytes only (no histogram
         # re-read of the keys: the histograms read the digit bytes)
         n_sym, act = st["n_total"], st["active_per_round"]
-        # counted scatter launches (records + the digit bytes they write), + the partition pass that computes the ranks
-        # (RankVals: sorted key 4 + position 4 read, pair 8 + digit byte written), + the digit bytes the histograms read
-        # (every byte written once is read once; the first pass's bytes come from the key builder: written + read),
-        # or the keys the histograms re-read where there are no digit bytes
-        pass_bytes = radix_bytes / steps + (17 * n_sym if st["rank_in_pass"] else 0)
-        # (the key builder's digit bytes — written + read — unless it took the first histogram itself)
-        dig_read = (digit_bytes / steps + (n_sym if st["rank_in_pass"] else 0) + (0 if st["hist_in_keys"] else 2 * n_sym)) if digit_bytes else key_bytes * radix_elems / steps
-        # no rank kernel of its own where the first partition pass computes the ranks (rank_in_pass) or where a suffix's
-        # slot is its rank (trie_refine: nothing asks for group heads)
-        split = 0 if (st["rank_in_pass"] or st["trie_refine"]) else SPLIT_BYTES - (4 if st["vocab_in_s"] == 0 else 0)
+        # counted scatter launches (records + the digit bytes they write) + the digit bytes the histograms read (every
+        # byte written once is read once; the first pass's bytes come from the key builder - written + read - unless it
+        # took the first histogram itself), or the keys the histograms re-read where there are no digit bytes
+        pass_bytes = radix_bytes / steps
+        dig_read = (digit_bytes / steps + (0 if st["hist_in_keys"] else 2 * n_sym)) if digit_bytes else key_bytes * radix_elems / steps
+        # no rank kernel of its own where a suffix's slot is its rank (trie_refine: nothing asks for group heads)
+        split = 0 if st["trie_refine"] else SPLIT_BYTES - (4 if st["vocab_in_s"] == 0 else 0)
         sa_bytes = pass_bytes + dig_read + (split + RANK_STORE_BYTES) * n_sym + ROUND_BYTES * sum(act[1:])
         dig = dig_read + (digit_bytes / steps if digit_bytes else 0)
         sa_ms = stage_ms.get("ms_sa", 0.0) / steps

@@ -15,12 +15,12 @@ import sys
 
 base, tag = sys.argv[1], sys.argv[2]
 ITEMS = 16  # WP_RADIX_ITEMS32: 32-bit round-0 keys, 8-byte records (round 1: <unsigned long, 24>)
-KEY = "radix_scatter_kernel<unsigned int, %d, wp::PlainVals>" % ITEMS  # (the plain scatter; RankVals also computes the ranks)
+KEY = "radix_scatter_kernel<unsigned int, %d, " % ITEMS  # (both instantiations: ranks by match-any / by LDS atomics in a sort's first pass)
 HIST = "radix_hist_kernel<unsigned int, %d>" % ITEMS
 
 
 def per_kernel(counter):
-    f = glob.glob(os.path.join(base, "%s_pmc_%s" % (tag, counter), "*counter_collection.csv"))[0]
+    f = glob.glob(os.path.join(base, "%s_pmc_%s" % (tag, counter), "**", "*counter_collection.csv"), recursive=True)[0]
     tot, cnt, grid = collections.Counter(), collections.Counter(), {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -34,7 +34,7 @@ def per_kernel(counter):
 
 ft, fc, fg = per_kernel("FETCH_SIZE")
 wt, wc, _ = per_kernel("WRITE_SIZE")
-names = [k for k in ft if KEY in k]  # (every value source of the full-size scatter: PlainVals, RankVals)
+names = [k for k in ft if KEY in k]
 # bench.py --steps 1 --warmup 1 encodes twice (+ once more for the oracle sample check): per-launch
 # averages do not depend on the number of steps
 launches = sum(fc[k] for k in names)
@@ -47,7 +47,7 @@ write = sum(wt[k] for k in names) / sum(wc[k] for k in names)
 bench = json.load(open(os.path.join(base, "%s_bench.json" % tag)))
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 out = {
-    "kernel": "radix_scatter_kernel<uint32, %d, PlainVals>" % ITEMS,
+    "kernel": "radix_scatter_kernel<uint32, %d, stable|first-pass>" % ITEMS,
     "round": tag,
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 "
               "--warmup 1 --no-cpu-baseline` (profiles/collect.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md "
