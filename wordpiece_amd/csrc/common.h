@@ -75,6 +75,10 @@ constexpr uint8_t kClsSpace = 1;    // is_space
 constexpr uint8_t kClsSpacing = 2;  // is_spacing_char
 constexpr uint8_t kClsSoft = 4;     // spacing char that occurs inside an eligible multi-char token
 constexpr uint8_t kClsPunct = 8;    // is_punctuation (the fast path's word rule, fast.cpp:56)
+// derived bits, merged into the class bytes by the Linear path's anchor kernels (walk.h) so that the walk reads ONE byte
+// per position it lands on: a word-prefix position (linear.cpp:215-219); an anchor of the walk (class or coverage rule)
+constexpr uint8_t kClsWordPrefix = 16;
+constexpr uint8_t kClsAnchor = 32;
 
 // ---- UTF-8: utf8.cpp:31-90 ----------------------------------------------------------------
 // Decodes the sequence starting at p[0] with `size` bytes available.  Returns the code point or

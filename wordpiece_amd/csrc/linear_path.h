@@ -88,6 +88,7 @@ struct LinearPath {
   int32_t *d_mid = nullptr, *d_rf = nullptr, *d_rb = nullptr, *d_cover_f = nullptr, *d_cover_b = nullptr;
   int32_t *d_tmin_f = nullptr, *d_tmin_b = nullptr, *d_gmin_f = nullptr, *d_gmin_b = nullptr, *d_pval_p = nullptr, *d_pval_s = nullptr;
   uint32_t *d_ps0 = nullptr, *d_ps1 = nullptr, *d_pv0 = nullptr, *d_pv1 = nullptr, *d_bidx = nullptr;
+  int2 *d_bfast = nullptr;
 
   // ---- state handed from stage to stage
   SymbolCode code;
@@ -117,7 +118,7 @@ struct LinearPath {
     sl_tiles = cdiv(n, kSlTile);
     sl_groups = cdiv(sl_tiles, kSlGroup);
     P = kStepsPerMark * M + 1;  // steps of the scanline result (scanline.h)
-    bucket_shift = std::max(0, bit_length(n) - 18);
+    bucket_shift = std::max(0, bit_length(n) - kStepBucketBits);
     nbuckets = static_cast<unsigned>(((n - 1) >> bucket_shift) + 1);
     radix_words = std::max(radix_tmp_words<uint64_t>(n), radix_tmp_words<uint32_t>(std::max<size_t>(n, kStepsPerMark * std::max(M, 1) + 1)));
     emit_tiles = cdiv(std::max<size_t>(n_text, 1), kScanTile);
@@ -261,6 +262,7 @@ struct LinearPath {
       d_pval_p = ar.take<int32_t>(P + 1);
       d_pval_s = ar.take<int32_t>(P + 1);
       d_bidx = ar.take<uint32_t>(static_cast<size_t>(nbuckets) + 2);
+      d_bfast = ar.take<int2>(static_cast<size_t>(nbuckets) + 1);
       if (pass == 0) ar.commit();
     }
     ar.arm(st);
@@ -743,8 +745,10 @@ struct LinearPath {
                        d_pval_p, d_pval_s, pack_steps);
     hipLaunchKernelGGL(piece_bucket_kernel, dim3(cdiv(nbuckets + 1, kBlock)), dim3(kBlock), 0, st, pstart, P, bucket_shift, nbuckets,
                        d_bidx);
+    hipLaunchKernelGGL(piece_bucket_fast_kernel, dim3(cdiv(nbuckets, kBlock)), dim3(kBlock), 0, st, d_bidx, d_pval_p, d_pval_s, nbuckets,
+                       d_bfast);
     WP_LAUNCH_CHECK();
-    steps = StepTable{pstart, d_pval_p, d_pval_s, d_bidx, bucket_shift, pack_steps};
+    steps = StepTable{pstart, d_pval_p, d_pval_s, d_bidx, bucket_shift, pack_steps, d_bfast};
   }
 
   // words longer than a lane should walk (walk.h, "long words"): pointer doubling instead.  Scratch: the slabs of the sort.
@@ -861,11 +865,11 @@ struct LinearPath {
                            c->d_scalars + 10, n_text, d_wide_list, c->d_scalars + 13);
         hipLaunchKernelGGL(walk_wide_kernel, dim3(std::min<size_t>(cdiv(acap, kBlock / kWave), 8192)), dim3(kBlock), 0, st, wa, d_anchors,
                            c->d_scalars + 10, d_wide_list, c->d_scalars + 13, d_wide_cnt);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_balanced_kernel<WalkArgs, LinearStep, true>), dim3(sblocks), dim3(kBlock), 0, st, wa,
-                           d_anchors, c->d_scalars + 10, acap, d_ctmp, d_blk_cnt, d_wide_cnt);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_lean_kernel<true>), dim3(sblocks), dim3(kBlock), 0, st, wa, d_anchors,
+                           c->d_scalars + 10, acap, d_ctmp, d_blk_cnt, d_wide_cnt);
       } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_balanced_kernel<WalkArgs, LinearStep, false>), dim3(sblocks), dim3(kBlock), 0, st, wa,
-                           d_anchors, c->d_scalars + 10, acap, d_ctmp, d_blk_cnt, static_cast<const uint32_t *>(nullptr));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_lean_kernel<false>), dim3(sblocks), dim3(kBlock), 0, st, wa, d_anchors,
+                           c->d_scalars + 10, acap, d_ctmp, d_blk_cnt, static_cast<const uint32_t *>(nullptr));
       }
       device_exclusive_scan(d_blk_cnt, d_blk_off, sblocks, d_emit_tmp, c->d_scalars + 9, st);
       hipLaunchKernelGGL(emit_gather_kernel, dim3(sblocks), dim3(kBlock), 0, st, d_anchors, c->d_scalars + 10, acap, d_ctmp, d_blk_cnt,
@@ -1005,7 +1009,7 @@ static void encode_on_device(const wp_vocab *v, Context *c, const uint8_t *d_tex
     d_tile_cnt = aa.take<uint32_t>(dec_tiles + 1);
     d_cnt_tmp = aa.take<uint32_t>(cdiv(dec_tiles, kScanTile) + 8);
     d_cps = v->keep_debug ? aa.take<uint32_t>(nbytes + 1) : nullptr;  // raw code points: debug copy only
-    d_cls = aa.take<uint8_t>(nbytes + 1);
+    d_cls = aa.take<uint8_t>(nbytes + 32);  // (the walk reads 16 class bytes from any position on)
     if (pass == 0) aa.commit();
   }
   aa.arm(st);

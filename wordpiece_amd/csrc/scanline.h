@@ -26,6 +26,10 @@ constexpr int kSlTile = kBlock * kSlItems;  // 4096 SA slots per workgroup
 constexpr int32_t kLcpInf = 0x7fffffff;
 constexpr uint32_t kMarkLenMask = 0x0fffffffu;
 // step values with the token length packed above the id: ids < 2^20 lines, lengths < 2^11 symbols (the sign bit stays clear)
+#ifndef WP_STEP_BUCKET_BITS
+#define WP_STEP_BUCKET_BITS 18
+#endif
+constexpr int kStepBucketBits = WP_STEP_BUCKET_BITS;  // the step table's index: at most 2^bits buckets of SA slots
 constexpr int kStepIdBits = 20;
 constexpr int kStepMaxLen = 1 << 11;
 constexpr uint32_t kMarkSurvBwd = 1u << 28;  // on the stack when the right->left scan leaves the tile
@@ -438,12 +442,31 @@ __global__ __launch_bounds__(kBlock) void piece_bucket_kernel(const uint32_t *__
   bidx[b] = static_cast<uint32_t>(lo);
 }
 
+// bfast[b]: the two values of the one step that covers bucket b — or, when steps start inside the bucket,
+// {kStepSlow | their number, index of the first of them}: the walk's lookup is rank -> this entry (one 8-byte load)
+// for most slots, and a short binary search over those few starts plus one value load for the others, instead of
+// rank -> bucket pair -> starts -> value.  (Measured and dropped: a 32-byte record per bucket with one or two inner
+// starts, which makes the second case one more load as well — the walk was 4 % slower with it.)
+constexpr int32_t kStepSlow = static_cast<int32_t>(0x80000000u);  // (values are -1 or >= 0; a slow entry is < -1)
+__global__ __launch_bounds__(kBlock) void piece_bucket_fast_kernel(const uint32_t *__restrict__ bidx,
+                                                                   const int32_t *__restrict__ pval_prefix,
+                                                                   const int32_t *__restrict__ pval_suffix, unsigned nbuckets,
+                                                                   int2 *__restrict__ bfast) {
+  const unsigned b = blockIdx.x * kBlock + threadIdx.x;
+  if (b >= nbuckets) return;
+  const uint32_t lo = bidx[b], hi = bidx[b + 1];
+  // (bucket 0 holds step 0, which starts at slot 0: lo == hi implies lo > 0)
+  bfast[b] = lo == hi ? int2{pval_prefix[lo - 1], pval_suffix[lo - 1]}
+                      : int2{kStepSlow | static_cast<int32_t>(hi - lo), static_cast<int32_t>(lo)};
+}
+
 struct StepTable {
   const uint32_t *pstart;
   const int32_t *pval_prefix, *pval_suffix;
   const uint32_t *bidx;
   int shift;
   int packed;  // values are (token length << kStepIdBits) | id (-1 stays -1): vocabularies below the two limits
+  const int2 *bfast;
 };
 __device__ __forceinline__ int32_t step_id(const StepTable &st, int32_t raw) {
   return (st.packed && raw >= 0) ? (raw & ((1 << kStepIdBits) - 1)) : raw;
@@ -462,6 +485,19 @@ __device__ __forceinline__ int step_lookup(const StepTable &st, uint32_t r) {
     if (st.pstart[md] <= r) lo = md + 1; else hi = md;
   }
   return lo - 1;
+}
+
+// value of the step containing SA slot r, for a word-prefix position or not (linear.cpp:243-250's two arrays)
+__device__ __forceinline__ int32_t step_raw(const StepTable &st, uint32_t r, bool prefix) {
+  const int2 e = st.bfast[r >> st.shift];
+  if (e.x >= -1) return prefix ? e.x : e.y;
+  const int n = e.x & 0x7fffffff;
+  int lo = e.y, hi = e.y + n;
+  while (lo < hi) {  // first step of the bucket with start > r
+    const int md = (lo + hi) >> 1;
+    if (st.pstart[md] <= r) lo = md + 1; else hi = md;
+  }
+  return prefix ? st.pval_prefix[lo - 1] : st.pval_suffix[lo - 1];
 }
 
 // debug / parity: expand the step functions to the reference's per-slot arrays

@@ -97,25 +97,38 @@ struct WalkState {
   size_t p, since;  // position; start of the tokens counted by tokens_since_prefix
 };
 
+// The class bytes of positions p-1 .. p+14 in two registers, loaded next to the rank (a token is a chain of
+// dependent loads: every class test behind the token's end would otherwise add a link to it)
+struct StepWin {
+  uint64_t w0, w1;
+  size_t wbase;
+  bool win;
+};
+__device__ __forceinline__ StepWin step_window(const WalkArgs &a, size_t p) {
+  StepWin W{0, 0, p ? p - 1 : 0, false};
+  W.win = W.wbase + 16 <= a.n_text;
+  if (W.win) {
+    __builtin_memcpy(&W.w0, a.cls + W.wbase, 8);
+    __builtin_memcpy(&W.w1, a.cls + W.wbase + 8, 8);
+  }
+  return W;
+}
+__device__ __forceinline__ uint8_t step_cb(const WalkArgs &a, const StepWin &W, size_t q) {
+  const size_t d = q - W.wbase;
+  if (W.win && d < 16) return static_cast<uint8_t>((d < 8 ? W.w0 >> (8 * d) : W.w1 >> (8 * (d - 8))) & 0xffu);
+  return a.cls[q];
+}
+__device__ __forceinline__ bool step_word_prefix(const WalkArgs &a, const StepWin &W, size_t q) {
+  return q == 0 || (step_cb(a, W, q) & kClsSpacing) || (step_cb(a, W, q - 1) & kClsSpacing);
+}
+
+// the part of a step behind the lookup: raw = the step table's value for s.p (step_raw)
 template <typename Out>
-__device__ __forceinline__ bool walk_step(const WalkArgs &a, WalkState &s, Out &o) {
+__device__ __forceinline__ bool walk_finish(const WalkArgs &a, WalkState &s, Out &o, const StepWin &W, int32_t raw) {
   const size_t end = a.n_text;
   size_t p = s.p;
-  // The class bytes of positions p-1 .. p+14 in two registers, loaded next to the rank (a token is a chain of
-  // dependent loads: every class test behind the token's end would otherwise add a link to it)
-  const size_t wbase = p ? p - 1 : 0;
-  uint64_t w0 = 0, w1 = 0;
-  const bool win = wbase + 16 <= end;
-  if (win) {
-    __builtin_memcpy(&w0, a.cls + wbase, 8);
-    __builtin_memcpy(&w1, a.cls + wbase + 8, 8);
-  }
-  auto cb = [&](size_t q) -> uint8_t {
-    const size_t d = q - wbase;
-    if (win && d < 16) return static_cast<uint8_t>((d < 8 ? w0 >> (8 * d) : w1 >> (8 * (d - 8))) & 0xffu);
-    return a.cls[q];
-  };
-  auto word_prefix = [&](size_t q) { return q == 0 || (cb(q) & kClsSpacing) || (cb(q - 1) & kClsSpacing); };
+  auto cb = [&](size_t q) -> uint8_t { return step_cb(a, W, q); };
+  auto word_prefix = [&](size_t q) { return step_word_prefix(a, W, q); };
   auto space = [&](size_t q) { return (cb(q) & kClsSpace) != 0; };
   auto anchor = [&](size_t q) {
     if (a.aflags) return a.aflags[q] != 0;
@@ -123,10 +136,6 @@ __device__ __forceinline__ bool walk_step(const WalkArgs &a, WalkState &s, Out &
     if (c & kClsSpace) return false;
     return q == 0 || w_hard(c) || w_hard(cb(q - 1));
   };
-  const bool prefix = word_prefix(p);
-  const uint32_t r = rank_of(a.rank[p]);
-  const int k = step_lookup(a.steps, r);
-  const int32_t raw = prefix ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k];
   int32_t id = step_id(a.steps, raw);
   if (!wp_in_bounds(id >= -1 && id < a.n_tokens, kSiteTokenId)) id = -1;
   if (id != -1) {
@@ -175,6 +184,13 @@ __device__ __forceinline__ bool walk_step(const WalkArgs &a, WalkState &s, Out &
     o.word_start();
   }
   return false;
+}
+
+template <typename Out>
+__device__ __forceinline__ bool walk_step(const WalkArgs &a, WalkState &s, Out &o) {
+  const StepWin W = step_window(a, s.p);
+  const uint32_t r = rank_of(a.rank[s.p]);
+  return walk_finish(a, s, o, W, step_raw(a.steps, r, step_word_prefix(a, W, s.p)));
 }
 
 template <typename Out>
@@ -249,14 +265,45 @@ __global__ __launch_bounds__(kBlock) void anchor_count_kernel(const uint8_t *__r
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
 }
 
-// the list stays in text order: lane offsets come from a workgroup scan of the per-lane counts
-__global__ __launch_bounds__(kBlock) void anchor_write_kernel(const uint8_t *__restrict__ cls,
-                                                              const uint8_t *__restrict__ aflags, size_t n,
-                                                              const uint32_t *__restrict__ tile_prefix,
+// the list stays in text order: lane offsets come from a workgroup scan of the per-lane counts.  The kernel also merges
+// what it knows into the class bytes (kClsWordPrefix, kClsAnchor): the walk then needs one byte of the position it
+// lands on instead of that byte, its neighbour and (coverage rule) the flag array.
+__global__ __launch_bounds__(kBlock) void anchor_write_kernel(uint8_t *__restrict__ cls, const uint8_t *__restrict__ aflags,
+                                                              size_t n, const uint32_t *__restrict__ tile_prefix,
                                                               uint32_t *__restrict__ anchors) {
   __shared__ uint32_t sm[8];
   const size_t i = static_cast<size_t>(blockIdx.x) * kAnchorTile + static_cast<size_t>(threadIdx.x) * kAnchorBytes;
   uint32_t m = anchor_mask16(cls, aflags, n, i);
+  if (i < n) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    const int cnt = static_cast<int>(min(static_cast<size_t>(kAnchorBytes), n - i));
+    if (cnt == kAnchorBytes) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(cls + i);
+      w[0] = v.x;
+      w[1] = v.y;
+      w[2] = v.z;
+      w[3] = v.w;
+    } else {
+      for (int j = 0; j < cnt; j++) w[j >> 2] |= static_cast<uint32_t>(cls[i + j]) << (8 * (j & 3));
+    }
+    uint32_t spc = 0;  // bit j: position i + j is a spacing char
+#pragma unroll
+    for (int q = 0; q < 4; q++) spc |= ((((w[q] >> 1) & 0x01010101u) * 0x01020408u) >> 24) << (4 * q);
+    const uint32_t before = i == 0 ? 1u : ((cls[i - 1] & kClsSpacing) ? 1u : 0u);  // (the neighbour's low bits never change)
+    const uint32_t wp = (spc | (spc << 1) | before) & 0xffffu;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      // 4 mask bits -> bit 0 of 4 bytes
+      const uint32_t wq = (((wp >> (4 * q)) & 15u) * 0x00204081u) & 0x01010101u;
+      const uint32_t aq = (((m >> (4 * q)) & 15u) * 0x00204081u) & 0x01010101u;
+      w[q] = (w[q] & 0x0f0f0f0fu) | (wq << 4) | (aq << 5);
+    }
+    if (cnt == kAnchorBytes) {
+      *reinterpret_cast<uint4 *>(cls + i) = uint4{w[0], w[1], w[2], w[3]};
+    } else {
+      for (int j = 0; j < cnt; j++) cls[i + j] = static_cast<uint8_t>(w[j >> 2] >> (8 * (j & 3)));
+    }
+  }
   uint32_t tot;
   uint32_t o = tile_prefix[blockIdx.x] + block_excl_sum(static_cast<uint32_t>(__popc(m)), sm, tot);
   while (m) {
@@ -363,9 +410,8 @@ __global__ __launch_bounds__(kBlock) void reach_kernel(WalkArgs a, uint32_t *__r
     if (q < a.n_text) {
       uint32_t r = static_cast<uint32_t>(q);
       if (!w_space(a, q)) {
-        const int k = step_lookup(a.steps, rank_of(a.rank[q]));
-        const int32_t id = step_id(a.steps, w_word_prefix(a, q) ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k]);
-        if (id != -1) r += static_cast<uint32_t>(a.tok_len[id]);
+        const int32_t raw = step_raw(a.steps, rank_of(a.rank[q]), (a.cls[q] & kClsWordPrefix) != 0);
+        if (step_id(a.steps, raw) != -1) r += static_cast<uint32_t>(step_len(a.steps, raw, a.tok_len));
       }
       reach[q] = r;
       mx = max(mx, r);
@@ -541,11 +587,11 @@ __global__ __launch_bounds__(kBlock) void long_word_next_kernel(WalkArgs a, cons
   int32_t id = -2;
   uint32_t nx = j;
   if (!w_space(a, p)) {
-    const int k = step_lookup(a.steps, rank_of(a.rank[p]));
-    id = step_id(a.steps, w_word_prefix(a, p) ? a.steps.pval_prefix[k] : a.steps.pval_suffix[k]);
+    const int32_t raw = step_raw(a.steps, rank_of(a.rank[p]), (a.cls[p] & kClsWordPrefix) != 0);
+    id = step_id(a.steps, raw);
     if (id != -1) {
-      const size_t q = p + static_cast<size_t>(a.tok_len[id]);
-      if (q < lw.end) nx = j + static_cast<uint32_t>(a.tok_len[id]);  // (q == end: the last token of the range)
+      const uint32_t len = static_cast<uint32_t>(step_len(a.steps, raw, a.tok_len));
+      if (p + len < lw.end) nx = j + len;  // (p + len == end: the last token of the range)
     }
   }
   id_out[j] = id;
@@ -656,14 +702,18 @@ __global__ __launch_bounds__(kBlock) void walk_wide_kernel(WalkArgs a, const uin
     const uint32_t k = list[wi];
     const uint32_t start = anchors[k];
     const uint32_t next = static_cast<size_t>(k) + 1 < na ? anchors[k + 1] : static_cast<uint32_t>(a.n_text);
-    uint32_t e = next;  // the word ends at the first space of the stretch
-    for (uint32_t base = start; base < next; base += kWave) {
-      const uint32_t q = base + lane;
-      const uint64_t m = __ballot(q < next && (a.cls[q] & kClsSpace));
+    // the word ends where the blanks of the stretch begin (under this rule a stretch is one word and the blanks behind
+    // it: looked for from the back — usually one load instead of one per 64 characters of the word)
+    uint32_t e = next;
+    while (e > start) {
+      const uint32_t q = e - 1 - static_cast<uint32_t>(lane);
+      const bool in = e - start > static_cast<uint32_t>(lane);
+      const uint64_t m = __ballot(in && !(a.cls[q] & kClsSpace));  // bit j: position e-1-j is not a blank
       if (m) {
-        e = base + static_cast<uint32_t>(__ffsll(static_cast<long long>(m)) - 1);
+        e -= static_cast<uint32_t>(__ffsll(static_cast<long long>(m)) - 1);
         break;
       }
+      e -= min(e - start, static_cast<uint32_t>(kWave));
     }
     int32_t *out = a.emit + start;
     uint32_t c = 0;
@@ -679,8 +729,7 @@ __global__ __launch_bounds__(kBlock) void walk_wide_kernel(WalkArgs a, const uin
         id[j] = -1;
         jp[j] = kEnd;
         if (q < e) {
-          const int st = step_lookup(a.steps, rank_of(a.rank[q]));
-          const int32_t raw = w_word_prefix(a, q) ? a.steps.pval_prefix[st] : a.steps.pval_suffix[st];
+          const int32_t raw = step_raw(a.steps, rank_of(a.rank[q]), (a.cls[q] & kClsWordPrefix) != 0);
           int32_t t = step_id(a.steps, raw);
           if (!wp_in_bounds(t >= -1 && t < a.n_tokens, kSiteTokenId)) t = -1;
           id[j] = t;
@@ -731,6 +780,34 @@ __global__ __launch_bounds__(kBlock) void walk_wide_kernel(WalkArgs a, const uin
     }
     if (lane == 0) wide_cnt[k] = c | kWideFlag;
   }
+}
+
+// the lists of a workgroup's words, one behind the other, at ctmp[position of its first anchor ...]: thread t
+// appends words kPer * t ... (cnt[w]: ids of word w, | kWideFlag: all of them in the word's own stretch of emit)
+template <int WORDS, bool WIDE>
+__device__ __forceinline__ void assemble_word_lists(const int32_t *__restrict__ emit, const uint32_t *__restrict__ anchors, size_t a0,
+                                                    size_t na, const int32_t *stage, const uint32_t *cnt, uint32_t *sm,
+                                                    int32_t *__restrict__ ctmp, uint32_t *__restrict__ blk_cnt) {
+  constexpr int kPer = WORDS / kBlock;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int q = 0; q < kPer; q++) mine += cnt[threadIdx.x * kPer + q] & (WIDE ? ~kWideFlag : ~0u);
+  uint32_t tot;
+  uint32_t ex = block_excl_sum(mine, sm, tot);
+  const size_t base = a0 < na ? anchors[a0] : 0;
+#pragma unroll
+  for (int q = 0; q < kPer; q++) {
+    const int wq = threadIdx.x * kPer + q;
+    const uint32_t c = cnt[wq] & (WIDE ? ~kWideFlag : ~0u);
+    const uint32_t staged = (WIDE && (cnt[wq] & kWideFlag)) ? 0u : static_cast<uint32_t>(kStageIds);  // (a wide word: everything in its stretch)
+    if (c == 0) continue;
+    const int32_t *spill = c > staged ? emit + anchors[a0 + wq] : nullptr;
+    for (uint32_t j = 0; j < c; j++) {
+      ctmp[base + ex + j] = j < staged ? stage[j * WORDS + wq] : spill[j];
+    }
+    ex += c;
+  }
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
 }
 
 // A lane per word makes every wave wait for its longest word: 1.2 tokens per word on average, 7 in the slowest of
@@ -807,27 +884,130 @@ __global__ __launch_bounds__(kBlock) void walk_balanced_kernel(Args a, const uin
     if (!__ballot(active) && (!WIDE || next >= kWbPerWave)) break;
   }
   __syncthreads();
-  // the lists of the words, one behind the other: thread t appends words kPer * t ...
-  constexpr int kPer = kWbWords / kBlock;
-  uint32_t mine = 0;
-#pragma unroll
-  for (int q = 0; q < kPer; q++) mine += cnt[threadIdx.x * kPer + q] & (WIDE ? ~kWideFlag : ~0u);
-  uint32_t tot;
-  uint32_t ex = block_excl_sum(mine, sm, tot);
-  const size_t base = a0 < na ? anchors[a0] : 0;
-#pragma unroll
-  for (int q = 0; q < kPer; q++) {
-    const int wq = threadIdx.x * kPer + q;
-    const uint32_t c = cnt[wq] & (WIDE ? ~kWideFlag : ~0u);
-    const uint32_t staged = (WIDE && (cnt[wq] & kWideFlag)) ? 0u : static_cast<uint32_t>(kStageIds);  // (a wide word: everything in its stretch)
-    if (c == 0) continue;
-    const int32_t *spill = c > staged ? a.emit + anchors[a0 + wq] : nullptr;
-    for (uint32_t j = 0; j < c; j++) {
-      ctmp[base + ex + j] = j < staged ? stage[j * kWbWords + wq] : spill[j];
+  assemble_word_lists<kWbWords, WIDE>(a.emit, anchors, a0, na, stage, cnt, sm, ctmp, blk_cnt);
+}
+
+// The Linear walk, lean.  The kernel above is generic (Fast and Linear steps) and its Linear step is instruction bound,
+// not memory bound: 200 vector + 150 scalar instructions per token step (class tests through two 64-bit windows,
+// 64-bit positions, the step table's search), with 7 waves per SIMD all wanting the issue port (SQ counters:
+// 12 % of a wave's life issuing x 7 waves).  Here the common step is straight: the rank and 16 class bytes from p on
+// are loaded together, the step table answers from its bucket entry (scanline.h, step_raw), the class byte of the
+// landing position — which carries its word-prefix and anchor bits (anchor_write_kernel) — comes out of the 16 by
+// one field extract, positions are 32-bit.  Everything else (no token: [UNK] and roll back; blank runs; a landing
+// position beyond the window) goes through the generic walk_finish, which redoes the step from the same state.
+template <bool WIDE>
+__global__ __launch_bounds__(kBlock) void walk_lean_kernel(WalkArgs a, const uint32_t *__restrict__ anchors,
+                                                           const uint32_t *__restrict__ n_anchors_dev, size_t cap,
+                                                           int32_t *__restrict__ ctmp, uint32_t *__restrict__ blk_cnt,
+                                                           const uint32_t *__restrict__ wide_cnt) {
+  __shared__ int32_t stage[kStageIds * kWbWords];
+  __shared__ uint32_t cnt[kWbWords];
+  __shared__ uint32_t sm[8];
+  const int lane = lane_id(), w = wave_id();
+  const size_t na = min(cap, static_cast<size_t>(*n_anchors_dev));
+  const size_t a0 = static_cast<size_t>(blockIdx.x) * kWbWords;
+  const uint32_t end = static_cast<uint32_t>(a.n_text);
+  for (int q = threadIdx.x; q < kWbWords; q += kBlock) cnt[q] = 0;
+  __syncthreads();
+  const int wbase = w * kWbPerWave;
+  const int mine = a0 + static_cast<size_t>(wbase) < na
+                       ? static_cast<int>(min(static_cast<size_t>(kWbPerWave), na - a0 - static_cast<size_t>(wbase)))
+                       : 0;  // words of this wave that exist
+  const bool stop_at_blank = !a.aflags && a.all_hard;  // (walk_finish: the position behind the blanks is an anchor of its own)
+  int widx = wbase + lane;
+  uint32_t p = 0, since = 0;
+  StagedOut o{stage + widx, a.emit, 0, 0, kWbWords};
+  // a word is taken: where it starts; false: a wide word (walk_wide_kernel has its ids), nothing to walk
+  auto take = [&](int wd) {
+    widx = wd;
+    const size_t k = a0 + static_cast<size_t>(wd);
+    const uint32_t start = anchors[k];
+    p = since = start;
+    o = StagedOut{stage + wd, a.emit + start, 0, 0, kWbWords};
+    if (WIDE) {
+      const uint32_t hi = k + 1 < static_cast<size_t>(*n_anchors_dev) ? anchors[k + 1] : end;
+      if (hi - start > kWideMin) {
+        cnt[wd] = wide_cnt[k];
+        return false;
+      }
     }
-    ex += c;
+    return true;
+  };
+  bool active = lane < mine && take(wbase + lane);
+  int next = min(kWave, mine);  // next word of the wave (relative to wbase) that no lane has taken
+  for (;;) {
+    if (active) {
+      bool done = true;
+      if (p < end) {
+        const uint32_t r = rank_of(a.rank[p]);
+        uint32_t cw[4];  // class bytes of p .. p + 15 (the array has 16 bytes of slack behind the text)
+        __builtin_memcpy(cw, a.cls + p, 16);
+        const int32_t raw = step_raw(a.steps, r, (cw[0] & kClsWordPrefix) != 0);
+        const int32_t id = step_id(a.steps, raw);
+        bool fast = id >= 0 && wp_in_bounds(id < a.n_tokens, kSiteTokenId);
+        uint32_t len = 0, p2 = 0, f = 0;
+        if (fast) {
+          len = static_cast<uint32_t>(step_len(a.steps, raw, a.tok_len));
+          p2 = p + len;
+          fast = len < 15 || p2 >= end;  // (the landing position and the one behind it inside the window)
+        }
+        if (fast && p2 < end) {
+          const uint32_t d0 = len < 8 ? (len < 4 ? cw[0] : cw[1]) : (len < 12 ? cw[2] : cw[3]);
+          f = __builtin_amdgcn_ubfe(d0, (len & 3u) * 8u, 8u);
+          if (f & kClsSpace) {
+            if (!stop_at_blank) {
+              // one blank and the position behind it (the usual case between two words); longer runs: generic path
+              const uint32_t l1 = len + 1;
+              const uint32_t d1 = l1 < 8 ? (l1 < 4 ? cw[0] : cw[1]) : (l1 < 12 ? cw[2] : cw[3]);
+              const uint32_t f1 = __builtin_amdgcn_ubfe(d1, (l1 & 3u) * 8u, 8u);
+              if (p2 + 1 < end && !(f1 & kClsSpace)) {
+                p2 += 1;
+                f = f1;
+              } else {
+                fast = p2 + 1 >= end;  // (blanks up to the end of the text: done)
+                f = kClsAnchor;
+                if (fast) p2 = end;
+              }
+            } else {
+              f = kClsAnchor;  // (done: the next anchor is the first position behind the blanks)
+            }
+          }
+        }
+        if (fast) {
+          o.push(p, id);
+          p = p2;
+          done = p2 >= end || (f & kClsAnchor);
+          if (!done && (f & kClsWordPrefix)) {
+            since = p2;
+            o.word_start();
+          }
+        } else {
+          WalkState s{p, since};
+          const StepWin W = step_window(a, p);
+          done = walk_finish(a, s, o, W, raw);
+          p = static_cast<uint32_t>(s.p);
+          since = static_cast<uint32_t>(s.since);
+        }
+      }
+      if (done) {
+        cnt[widx] = o.c;
+        active = false;
+      }
+    }
+    // the idle lanes pick the next words in order (ballot + prefix count, no atomics)
+    const uint64_t idle = __ballot(!active);
+    if (next < mine) {  // (wave-uniform)
+      if (!active) {
+        const int cand = next + __popcll(idle & ((1ull << lane) - 1ull));
+        if (cand < mine) active = take(wbase + cand);
+      }
+      next = min(next + static_cast<int>(__popcll(idle)), mine);
+    }
+    // (a lane that was dealt a wide word is idle again at once: the wave is done when nobody walks AND no word is left)
+    if (!__ballot(active) && next >= mine) break;
   }
-  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
+  __syncthreads();
+  assemble_word_lists<kWbWords, WIDE>(a.emit, anchors, a0, na, stage, cnt, sm, ctmp, blk_cnt);
 }
 
 // ids[blk_off[b] ...] = the list of workgroup b (of the walk kernel, which took `words` anchors per workgroup)
