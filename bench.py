@@ -318,7 +318,7 @@ def main():
         key_bytes = 4 if 0 < st["key_bits"] <= 32 else 8
         RADIX_BYTES_PER_ELEM = 2 * (key_bytes + 4)
         scatter_name = "radix_scatter_kernel<%s, stable|first-pass> (full-size tiles: the %d passes of the round-0 suffix sort over %d-bit keys%s; %d-byte records)" % (
-            "uint32, 16" if key_bytes == 4 else "uint64, 24", (st["key_bits"] + 7) // 8, st["key_bits"],
+            "uint32, 20" if key_bytes == 4 else "uint64, 24", (st["key_bits"] + 7) // 8, st["key_bits"],
             " and the two destination-partition passes of the round-0 rank store (the first one makes its value column - the slots - up)"
             if key_bytes == 4 else "", key_bytes + 4)
         ms_per_step = dt_max / args.steps * 1e3

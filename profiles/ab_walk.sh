@@ -12,7 +12,7 @@ for CFG in ${CFGS:-2 3 5}; do
     python - <<PY
 import json
 d=json.load(open("gpurun_out/${TAG}_${CFG}_$V.json"))
-print("config $CFG $V", d["ms_per_step"], d["stage_ms_per_step"])
+print("config $CFG $V", d["ms_per_step"], d["stage_ms_per_step"], "scatter launch ms", d["roofline"]["avg_launch_ms"], "frac", d["roofline"]["frac"])
 PY
   done
 done

@@ -14,7 +14,7 @@ import os
 import sys
 
 base, tag = sys.argv[1], sys.argv[2]
-ITEMS = 16  # WP_RADIX_ITEMS32: 32-bit round-0 keys, 8-byte records (round 1: <unsigned long, 24>)
+ITEMS = 20  # WP_RADIX_ITEMS32: 32-bit round-0 keys, 8-byte records (round 1: <unsigned long, 24>)
 KEY = "radix_scatter_kernel<unsigned int, %d, " % ITEMS  # (both instantiations: ranks by match-any / by LDS atomics in a sort's first pass)
 HIST = "radix_hist_kernel<unsigned int, %d>" % ITEMS
 

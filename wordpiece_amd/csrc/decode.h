@@ -645,27 +645,32 @@ __global__ __launch_bounds__(kBlock) void build_keys0_kernel(const SymT *__restr
 // kKeys8MinLen bits (17 x 2 >= 32; a code with a 1-bit codeword, a text dominated by one character, keeps the
 // generic kernel above).
 constexpr int kKeys8Items = 16;
-constexpr int kKeys8Tile = kBlock * kKeys8Items;
+constexpr int kKeys8Tile = RadixCfg<Key0>::kTile;          // the key builder's tiles are the tiles of the round-0 sort,
+constexpr int kKeys8Threads = kKeys8Tile / kKeys8Items;   // its workgroups as many lanes as that takes (20 keys per sort lane: 320)
+static_assert(kKeys8Threads * kKeys8Items == kKeys8Tile && kKeys8Threads % kWave == 0 && kKeys8Threads >= 256 && kKeys8Threads <= 1024,
+              "a whole number of waves, and at least the 256 lanes that load the code table and write the histogram row");
 constexpr int kKeys8MinLen = (kKeyBits + kKeys8Items) / (kKeys8Items + 1);
-// hist_table != nullptr: the tile of this workgroup is a tile of the round-0 sort (4096 keys): the histogram of the
+// hist_table != nullptr: the tile of this workgroup is a tile of the round-0 sort: the histogram of the
 // sort's first digit — the low byte of the keys — is taken right here (per-wave LDS counters: the tail of a compressed
 // codeword stream is near-uniform) and written as that sort's tile row and chunk sums (radix_sort.h, RadixPlan): one
 // launch and one byte written and read per key less than through the digit bytes (dig0 is nullptr then).
-__global__ __launch_bounds__(kBlock) void build_keys0_u8_kernel(const uint8_t *__restrict__ sym, size_t n, DevCode code,
+__global__ __launch_bounds__(kKeys8Threads) void build_keys0_u8_kernel(const uint8_t *__restrict__ sym, size_t n, DevCode code,
                                                                 Key0 *__restrict__ keys, uint8_t *__restrict__ dig0,
                                                                 uint32_t *__restrict__ hist_table,
                                                                 uint32_t *__restrict__ hist_chunk_sums) {
   static_assert(sizeof(Key0) == 4, "register form of the key builder: 32-bit keys");
-  static_assert(kKeys8Tile == RadixCfg<Key0>::kTile, "the key builder's tiles are the tiles of the round-0 sort");
   __shared__ uint32_t stab[256];  // (len << 16) | codeword
-  __shared__ uint32_t shist[kBlock / kWave][kRadixBins];
-  if (hist_table) {
-#pragma unroll
-    for (int i = 0; i < kBlock / kWave; i++) shist[i][threadIdx.x] = 0u;
-  }
+  constexpr int WAVES = kKeys8Threads / kWave;
+  __shared__ uint32_t shist[WAVES][kRadixBins];
   const int ub = code.uniform_bits > 0 ? code.uniform_bits : 0;
-  stab[threadIdx.x] = ub ? ((static_cast<uint32_t>(ub) << 16) | threadIdx.x)
-                         : ((static_cast<uint32_t>(code.len[threadIdx.x]) << 16) | code.cw[threadIdx.x]);
+  if (threadIdx.x < 256) {
+    if (hist_table) {
+#pragma unroll
+      for (int i = 0; i < WAVES; i++) shist[i][threadIdx.x] = 0u;
+    }
+    stab[threadIdx.x] = ub ? ((static_cast<uint32_t>(ub) << 16) | threadIdx.x)
+                           : ((static_cast<uint32_t>(code.len[threadIdx.x]) << 16) | code.cw[threadIdx.x]);
+  }
   __syncthreads();
   const size_t p0 = static_cast<size_t>(blockIdx.x) * kKeys8Tile + static_cast<size_t>(threadIdx.x) * kKeys8Items;
   // (the symbol buffer is 256-byte aligned and padded by 16 bytes behind n; positions at or behind n count as symbol 0)
@@ -726,11 +731,13 @@ __global__ __launch_bounds__(kBlock) void build_keys0_u8_kernel(const uint8_t *_
       if (p0 + j < n) atomicAdd(&shist[wv][k[j] & 0xffu], 1u);
     }
     __syncthreads();
-    uint32_t cnt = 0;
+    if (threadIdx.x < kRadixBins) {
+      uint32_t cnt = 0;
 #pragma unroll
-    for (int i = 0; i < kBlock / kWave; i++) cnt += shist[i][threadIdx.x];
-    hist_table[static_cast<size_t>(blockIdx.x) * kRadixBins + threadIdx.x] = cnt;
-    if (cnt) atomicAdd(&hist_chunk_sums[static_cast<size_t>(blockIdx.x / kColChunk) * kRadixBins + threadIdx.x], cnt);
+      for (int i = 0; i < WAVES; i++) cnt += shist[i][threadIdx.x];
+      hist_table[static_cast<size_t>(blockIdx.x) * kRadixBins + threadIdx.x] = cnt;
+      if (cnt) atomicAdd(&hist_chunk_sums[static_cast<size_t>(blockIdx.x / kColChunk) * kRadixBins + threadIdx.x], cnt);
+    }
   }
   if (p0 >= n) return;
   if (p0 + kKeys8Items <= n) {

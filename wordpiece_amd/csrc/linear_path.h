@@ -337,7 +337,7 @@ struct LinearPath {
         sort_plan = radix_plan<Key0>(n, d_radix_tmp, radix_words, st);
         hist_in_keys = true;
       }
-      hipLaunchKernelGGL(build_keys0_u8_kernel, dim3(cdiv(n, kKeys8Tile)), dim3(kBlock), 0, st,
+      hipLaunchKernelGGL(build_keys0_u8_kernel, dim3(cdiv(n, kKeys8Tile)), dim3(kKeys8Threads), 0, st,
                          reinterpret_cast<const uint8_t *>(d_sym), n, dcode, KA, hist_in_keys ? nullptr : DG0,
                          hist_in_keys ? sort_plan.table : nullptr, hist_in_keys ? sort_plan.chunk_sums0 : nullptr);
     } else {

@@ -34,7 +34,7 @@ struct RadixCfg {
 #define WP_RADIX_ITEMS64 24  // 6144-key tiles: 74 KB of LDS staging, two workgroups per CU (16 / 20 / 24: 13.78 / 13.73 / 13.69 ms)
 #endif
 #ifndef WP_RADIX_ITEMS32
-#define WP_RADIX_ITEMS32 16
+#define WP_RADIX_ITEMS32 20  // 5120-key tiles: 46 KB of LDS, three workgroups per CU (12 / 16 / 20 / 24: 0.402 / 0.403 / 0.389 / 0.418 ms per pass)
 #endif
   static constexpr int kItems = sizeof(KeyT) == 8 ? WP_RADIX_ITEMS64 : WP_RADIX_ITEMS32;
   static constexpr int kTile = kBlock * kItems;
