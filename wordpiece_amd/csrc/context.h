@@ -143,7 +143,9 @@ struct Context {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // side stream: latency-bound helpers overlap the bandwidth-bound kernels
-  hipEvent_t evs[5] = {};         // fork / join / scalars fetched / side stream done with the sorted keys / partition passes queued
+  hipStream_t stream3 = nullptr;  // second side stream: the large-group path of the trie round beside its LDS sort
+  hipEvent_t evs[7] = {};         // fork / join / scalars fetched / side stream done with the sorted keys / partition passes queued /
+                                  // trie nodes known / large groups sorted
   // vocab tables on the device
   uint32_t *d_stream = nullptr, *d_elig_start = nullptr, *d_elig_info = nullptr, *d_soft = nullptr;
   uint32_t *d_vocab_word_idx = nullptr, *d_vocab_word_bits = nullptr;  // the vocabulary's words of the alphabet bitmap
@@ -247,7 +249,7 @@ static void free_vocab_tables(Context *c) {
 // idempotent: every resource is cleared as it is released (runs from ~Context too)
 static void destroy_context(Context *c) {
   if (!c) return;
-  const bool owns = c->stream || c->stream2 || c->d_used || c->d_lut || c->d_scan_tmp || c->d_scalars || c->d_code ||
+  const bool owns = c->stream || c->stream2 || c->stream3 || c->d_used || c->d_lut || c->d_scan_tmp || c->d_scalars || c->d_code ||
                     c->d_symhist || c->h_scalars || c->h_code || c->d_stream || c->text_buf.p || c->a_buf.p ||
                     c->b_buf.p || c->fmt_buf.p;
   if (!owns) return;
@@ -286,9 +288,10 @@ static void destroy_context(Context *c) {
     if (e) (void)hipEventDestroy(e);
     e = nullptr;
   }
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  c->stream = c->stream2 = nullptr;
+  c->stream = c->stream2 = c->stream3 = nullptr;
 }
 Context::~Context() { destroy_context(this); }
 
@@ -333,7 +336,8 @@ static void park_context(std::unique_ptr<Context> c) {
   const bool no_pool = EnvOptions::get().no_pool;
   DeviceGuard keep;
   (void)hipSetDevice(c->device);
-  if (!no_pool && hipStreamSynchronize(c->stream) == hipSuccess && hipStreamSynchronize(c->stream2) == hipSuccess) {
+  if (!no_pool && hipStreamSynchronize(c->stream) == hipSuccess && hipStreamSynchronize(c->stream2) == hipSuccess &&
+      hipStreamSynchronize(c->stream3) == hipSuccess) {
     free_vocab_tables(c.get());
     if (c->text_buf.cap + c->text_buf2.cap + c->ids_stage[0].cap + c->ids_stage[1].cap + c->a_buf.cap + c->b_buf.cap + c->fmt_buf.cap >
         kPoolArenaBytes) {
@@ -410,6 +414,7 @@ static std::unique_ptr<Context> make_context(const wp_vocab *v, int device) {
   c->device = device;
   WP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   WP_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  WP_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
   for (auto &e : c->evs) WP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   WP_HIP(hipMalloc(&c->d_used, sizeof(uint32_t) * kCpWords));
   WP_HIP(hipMalloc(&c->d_lut, sizeof(uint32_t) * kCpTableSize));

@@ -533,39 +533,59 @@ __device__ __forceinline__ int count_key_symbols(uint64_t key, int t, const uint
   return cnt;
 }
 
-// First index in [lo, hi] whose key is >= key (hi: a position known to qualify, or the end of the array).  The
-// searches of this path are latency chains, not bandwidth: while the range is wide the whole wave probes 64 evenly
-// spaced positions with ONE load instruction and a ballot picks the stretch that holds the answer (3 steps from
-// 1e8 keys down to a few hundred, and the probes of the first two steps are the same cache lines for every search:
-// L2 hits); the last few hundred keys are finished by a binary search (a 64-way step there would pull in 64 lines
-// of its own per search where the binary search touches 3).  12 dependent loads instead of 27.
-// All 64 lanes must be active; every lane returns the same index.
-#ifndef WP_WAVE_SEARCH_NARROW
-#define WP_WAVE_SEARCH_NARROW 512
-#endif
-constexpr size_t kWaveSearchNarrow = WP_WAVE_SEARCH_NARROW;
-__device__ __forceinline__ size_t wave_key_lower_bound(const Key0 *__restrict__ keys, size_t lo, size_t hi, uint64_t key) {
-  const size_t lane = static_cast<size_t>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
-  while (hi - lo > kWaveSearchNarrow) {
-    const size_t st = (hi - lo) / kWave + 1;
-    const size_t idx = lo + lane * st;
-    const bool ge = idx < hi ? static_cast<uint64_t>(keys[idx]) >= key : true;
-    const uint64_t m = __ballot(ge);
-    if (!m) {  // (all 64 probes in range and below the key)
-      lo += (kWave - 1) * st + 1;
-      continue;
-    }
-    const size_t t = static_cast<size_t>(__ffsll(static_cast<long long>(m)) - 1);
-    const size_t first_ge = lo + t * st;
-    if (t) lo += (t - 1) * st + 1;
-    hi = first_ge < hi ? first_ge : hi;
-    if (!t) hi = lo;
+// First index in [lo, hi] whose key is >= key (hi: a position known to qualify, or the end of the array), by a whole
+// wave.  What a search costs here is the number of distinct 128-byte lines it pulls in (gather probe,
+// profiles/yardstick: ~1 ns of the CU's L1 fill per line from the L2, ~5 ns from HBM), not the length of its chain:
+// a step probes WAYS evenly spaced positions with one load and a ballot picks the stretch that holds the answer.
+// wide_steps 64-way steps first — worth their 64 lines only while all searches of a kernel probe the SAME lines (the
+// first two steps over the whole array: L2 hits) — then 8-way steps (7 lines each, 3 bits), the last 8 keys by a
+// binary search inside one or two lines.  All 64 lanes must be active; every lane returns the same index.
+template <int WAYS>
+__device__ __forceinline__ void wave_search_step(const Key0 *__restrict__ keys, size_t &lo, size_t &hi, uint64_t key, size_t lane) {
+  const size_t st = (hi - lo) / WAYS + 1;
+  const size_t idx = lo + lane * st;
+  const bool ge = (lane < static_cast<size_t>(WAYS) && idx < hi) ? static_cast<uint64_t>(keys[idx]) >= key : true;
+  const uint64_t m = __ballot(ge);
+  if (!m) {  // (WAYS == 64: all probes in range and below the key)
+    lo += (WAYS - 1) * st + 1;
+    return;
   }
+  const size_t t = static_cast<size_t>(__ffsll(static_cast<long long>(m)) - 1);
+  const size_t first_ge = lo + t * st;
+  if (t) lo += (t - 1) * st + 1;
+  hi = first_ge < hi ? first_ge : hi;
+  if (!t) hi = lo;
+}
+__device__ __forceinline__ size_t wave_key_lower_bound(const Key0 *__restrict__ keys, size_t lo, size_t hi, uint64_t key,
+                                                       int wide_steps) {
+  const size_t lane = static_cast<size_t>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+  for (int s = 0; s < wide_steps && hi - lo > 512; s++) wave_search_step<kWave>(keys, lo, hi, key, lane);
+  while (hi - lo > 8) wave_search_step<8>(keys, lo, hi, key, lane);
   while (lo < hi) {  // (uniform: the loads broadcast)
     const size_t md = (lo + hi) >> 1;
     if (static_cast<uint64_t>(keys[md]) < key) lo = md + 1; else hi = md;
   }
   return lo;
+}
+// First index in [from, n] whose key is >= key when the answer is expected near `from` (the end of an equal range that
+// starts there): lane j probes from + 2^j - 1 (16 lanes, then the other 16: a range of up to 32 K keys costs ~11
+// lines), the stretch between two probes is searched as above.
+__device__ __forceinline__ size_t wave_key_gallop(const Key0 *__restrict__ keys, size_t from, size_t n, uint64_t key) {
+  const size_t lane = static_cast<size_t>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+  for (int phase = 0; phase < 2; phase++) {
+    const size_t j = lane + 16u * static_cast<size_t>(phase);  // probe exponent of this lane (lanes >= 16: none)
+    const size_t idx = from + ((size_t(1) << (j & 31)) - 1);
+    const bool ge = (lane < 16 && idx < n) ? static_cast<uint64_t>(keys[idx]) >= key : true;
+    const uint64_t m = __ballot(ge);
+    const size_t t = static_cast<size_t>(__ffsll(static_cast<long long>(m)) - 1);  // (lanes >= 16 answer true: t <= 16)
+    if (t == 16 && phase == 0) continue;  // not within 2^15 keys: the far probes
+    const size_t e = t + 16u * static_cast<size_t>(phase);  // first exponent whose probe is >= key (or beyond n)
+    if (e == 0) return from;
+    const size_t lo = min(from + (size_t(1) << (e - 1)), n);  // (= the probe before it, + 1)
+    const size_t hi = e >= 32 ? n : max(lo, min(from + ((size_t(1) << e) - 1), n));
+    return wave_key_lower_bound(keys, lo, hi, key, 0);
+  }
+  return n;  // (not reached: the second phase always returns)
 }
 
 // Round-0 keys: the first 63 bits of the codeword stream of every suffix (most significant bit

@@ -553,6 +553,7 @@ struct LinearPath {
     // (sizes are read on the device: the launches do not wait for the host to learn them)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(trie_walk_kernel<SymT>), dim3(std::min<size_t>(cdiv(list_cap, kBlock), 16384)), dim3(kBlock), 0,
                        st2, avals, AG, d_gnode, d_gdone, c->d_scalars + 4, d_sym, n, d_vsym, trie, adep);
+    WP_HIP(hipEventRecord(c->evs[5], st2));  // (the large-group path starts from here, beside the LDS sort: trie_round_finish)
     hipLaunchKernelGGL(local_sort_kernel, dim3(cdiv(list_cap, kLsT)), dim3(kBlock), 0, st2, avals, AG, adep, c->d_scalars + 4,
                        d_ghead, d_rank, n, trie_rb(), LK0, spare_vals, adep);
   }
@@ -568,14 +569,18 @@ struct LinearPath {
     if (n_act > 0) {
       S.active_per_round[1] = static_cast<int64_t>(n_act);
       const int rb = trie_rb();
-      if (n_large > 0) {
+      if (n_large > 0) {  // (second side stream: other list positions than the LDS sort's, scratch of its own)
+        hipStream_t st3 = c->stream3;
+        WP_HIP(hipStreamWaitEvent(st3, c->evs[5], 0));
         const int lgb = bit_length(n_large_groups > 0 ? n_large_groups - 1 : 0);
-        hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(cdiv(n_large, kLxSpan), kBlock / kWave)), dim3(kBlock), 0, st2, avals, adep,
+        hipLaunchKernelGGL(large_extract_kernel, dim3(cdiv(cdiv(n_large, kLxSpan), kBlock / kWave)), dim3(kBlock), 0, st3, avals, adep,
                            d_lg_head, d_lg_off, static_cast<uint32_t>(n_large_groups), n_large, d_rank, n, rb, LK1, LV0, LPOS, adep);
         const int lc = radix_sort_pairs<uint64_t>(LK1, LV0, LK2, LV1, n_large, 0, rb + lgb, d_radix_tmp2,
-                                                  radix_tmp_words<uint64_t>(list_cap), st2, nullptr);
-        hipLaunchKernelGGL(large_writeback_kernel, dim3(std::min<size_t>(cdiv(n_large, kBlock), 8192)), dim3(kBlock), 0, st2,
+                                                  radix_tmp_words<uint64_t>(list_cap), st3, nullptr);
+        hipLaunchKernelGGL(large_writeback_kernel, dim3(std::min<size_t>(cdiv(n_large, kBlock), 8192)), dim3(kBlock), 0, st3,
                            lc ? LK2 : LK1, lc ? LV1 : LV0, LPOS, n_large, AG, rb, skeys, spare_vals);
+        WP_HIP(hipEventRecord(c->evs[6], st3));
+        WP_HIP(hipStreamWaitEvent(st2, c->evs[6], 0));
       }
       DepthRule rrule{need_depth, 0, nullptr, nullptr, 1, d_node_of_slot};  // final round: every group retires
       const unsigned tiles = cdiv(n_act, kRrTile);

@@ -120,10 +120,10 @@ __global__ __launch_bounds__(kBlock) void need_groups_kernel(const Key0 *__restr
   if (!is_long) {
     if (!rng_lo) return;
     // (the whole wave searches: wave_key_lower_bound)
-    const size_t lb = wave_key_lower_bound(keys, 0, n, key);
+    const size_t lb = wave_key_lower_bound(keys, 0, n, key, 2);
     const uint64_t step = 1ull << (kKeyBits - bits);
     const uint64_t above = key + step;  // first key that no longer starts with the stream
-    const size_t ubd = (bits == 0 || (above >> kKeyBits) != 0) ? n : wave_key_lower_bound(keys, lb, n, above);
+    const size_t ubd = (bits == 0 || (above >> kKeyBits) != 0) ? n : wave_key_gallop(keys, lb, n, above);
     if (lane == 0) {
       rng_lo[m] = static_cast<uint32_t>(lb);
       rng_hi[m] = static_cast<uint32_t>(ubd);
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(kBlock) void need_groups_kernel(const Key0 *__restr
     }
     return;
   }
-  const size_t first = wave_key_lower_bound(keys, 0, n, key);
-  const size_t last = wave_key_lower_bound(keys, first, n, key + 1);
+  const size_t first = wave_key_lower_bound(keys, 0, n, key, 2);
+  const size_t last = wave_key_gallop(keys, first, n, key + 1);
   if (last - first < 2) {  // no such suffix, or a single one: nothing to refine
     if (rng_lo && lane == 0) {
       size_t lb = first, ubd = first;

@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void round0_rank_kernel(const Key0 *__restr
           lo = hi >= back_t ? hi - back_t + 1 : 0;
           hi -= back_in;
         }
-        carry = wave_key_lower_bound(keys, lo, hi, static_cast<uint64_t>(me0));
+        carry = wave_key_lower_bound(keys, lo, hi, static_cast<uint64_t>(me0), 0);
       }
     }
     Key0 prev_last = __shfl(front, 0, kWave);  // key of the entry in front of the current step
