@@ -549,3 +549,38 @@ def test_needed_list_outgrows_its_room_and_the_encode_retries():
     assert np.array_equal(ids, exp)
     assert st["list_retries"] == 1 and st["needed_after_round0"] > st["n_total"] // 2
     assert np.array_equal(gv.encode(text), exp) and gv.stats()["list_retries"] == 0  # (the handle remembers)
+
+
+def test_lean_walk_paths():
+    """The lean walk (walk.h) answers the common step itself and hands the rest to the generic step: tokens of 15
+    symbols or more (the landing position lies outside its 16 class bytes), runs of blanks behind a token when
+    spacing chars occur inside tokens ("soft": no stop at the first blank), words without a token ([UNK] and the
+    roll-back), a text that ends in blanks, texts of fewer than 16 symbols.  Every case against the oracle."""
+    rng = random.Random(77)
+    letters = "abcdefghij"
+    stems = ["".join(rng.choice(letters) for _ in range(k)) for k in (1, 2, 3, 5, 8, 13, 14, 15, 16, 17, 24, 40)]
+    vocab = ["[UNK]"] + stems + ["##" + s for s in stems] + list(letters[:6]) + ["##" + c for c in letters[:6]]
+    soft = vocab + ["a-b", "##c-d", "e.f", "x-", "##-"]  # '-' and '.' inside tokens: soft spacing chars
+    for voc, name in ((vocab, "hard"), (soft, "soft")):
+        ov, gv = O.Vocab(voc), W.Vocab(voc)
+        for trial in range(120):
+            parts = []
+            for _ in range(rng.randint(1, 60)):
+                w = "".join(rng.choice(stems) for _ in range(rng.randint(1, 3)))
+                if rng.random() < 0.15:
+                    w += rng.choice(["q", "-", ".", "a-b", "zz"])  # pieces the vocabulary may not cover
+                parts.append(w)
+                parts.append(rng.choice([" ", " ", "  ", "   ", "\n", " \t ", "-", ". "]))
+            text = "".join(parts)
+            if trial % 3 == 0:
+                text = text.rstrip() + " " * rng.randint(1, 20)
+            if trial % 7 == 0:
+                text = text[:rng.randint(0, 15)]
+            t = text.encode("utf8")
+            assert np.array_equal(gv.encode(t), ov.encode(t)), (name, trial, text[:80])
+        # the same through the coverage rule
+        gv.set_option(W.WP_OPT_COVER_ANCHORS, 1)
+        for trial in range(40):
+            text = " ".join("".join(rng.choice(stems + ["-", "q"]) for _ in range(rng.randint(1, 4))) for _ in range(200))
+            t = text.encode("utf8")
+            assert np.array_equal(gv.encode(t), ov.encode(t)), (name, "cover", trial)

@@ -55,8 +55,8 @@ struct LinearPath {
   const HostVocab &hv;
   bool full, prune, use_trie, window_store, use_digit_bytes, staged_possible, sparse_emit;
   uint32_t need_depth;
-  int M, P, bucket_shift, hb_n, win_mid;
-  unsigned sl_tiles, sl_groups, nbuckets;
+  int M, P, bucket_shift, bucket_shift_all, hb_n, win_mid;
+  unsigned sl_tiles, sl_groups, nbuckets, nbuckets_all;
   size_t radix_words, emit_tiles, walk_blocks, claim_size, list_cap;
 
   // ---- device buffers.  n-sized "slabs" of 4 bytes per symbol change roles from stage to stage (see plan()).
@@ -88,7 +88,8 @@ struct LinearPath {
   int32_t *d_mid = nullptr, *d_rf = nullptr, *d_rb = nullptr, *d_cover_f = nullptr, *d_cover_b = nullptr;
   int32_t *d_tmin_f = nullptr, *d_tmin_b = nullptr, *d_gmin_f = nullptr, *d_gmin_b = nullptr, *d_pval_p = nullptr, *d_pval_s = nullptr;
   uint32_t *d_ps0 = nullptr, *d_ps1 = nullptr, *d_pv0 = nullptr, *d_pv1 = nullptr, *d_bidx = nullptr;
-  int2 *d_bfast = nullptr;
+  int2 *d_bfast = nullptr, *d_bfast_all = nullptr;
+  uint32_t *d_bidx_all = nullptr;
 
   // ---- state handed from stage to stage
   SymbolCode code;
@@ -102,7 +103,7 @@ struct LinearPath {
   uint32_t *avals = nullptr, *spare_vals = nullptr;
   bool classified = false;
   size_t n_act = 0, n_large = 0, n_large_groups = 0;
-  StepTable steps{};
+  StepTable steps{}, steps_all{};  // (steps_all: for the kernels that look up EVERY position of a stretch, scanlines())
 
   LinearPath(const wp_vocab *v_, Context *c_, wp_stats &S_, Arena &ar_, Arena &aa_, const uint8_t *text, size_t nb,
              const uint32_t *tile_prefix, size_t n_text_, size_t n_, uint32_t *cps, uint8_t *cls, int bits_, bool text_only_)
@@ -118,8 +119,16 @@ struct LinearPath {
     sl_tiles = cdiv(n, kSlTile);
     sl_groups = cdiv(sl_tiles, kSlGroup);
     P = kStepsPerMark * M + 1;  // steps of the scanline result (scanline.h)
-    bucket_shift = std::max(0, bit_length(n) - kStepBucketBits);
+    // buckets of the step table's index: about four per step (most lookups then end at the bucket entry, scanline.h)
+    const int bucket_bits = std::min(kStepBucketBitsMax, std::max(kStepBucketBits, bit_length(4 * static_cast<size_t>(P))));
+    bucket_shift = std::max(0, bit_length(n) - bucket_bits);
     nbuckets = static_cast<unsigned>(((n - 1) >> bucket_shift) + 1);
+    // ... and a second index of 2^18 buckets (2 MB: stays in the L2) for the kernels that look up every position of a
+    // long word, on the chain or not — their ranks spread over all slots, and 16 MB of entries miss the L2 (config 5:
+    // 13.0 against 11.0 ms; the coverage rule's reach kernel, whose positions nearly all ARE visited, is faster on the
+    // fine index: config 3, 9.3 against 9.8 ms)
+    bucket_shift_all = std::max(0, bit_length(n) - kStepBucketBits);
+    nbuckets_all = static_cast<unsigned>(((n - 1) >> bucket_shift_all) + 1);
     radix_words = std::max(radix_tmp_words<uint64_t>(n), radix_tmp_words<uint32_t>(std::max<size_t>(n, kStepsPerMark * std::max(M, 1) + 1)));
     emit_tiles = cdiv(std::max<size_t>(n_text, 1), kScanTile);
     walk_blocks = cdiv(std::max<size_t>(n_text, 1), kBlock);  // (at most one anchor per position)
@@ -263,6 +272,8 @@ struct LinearPath {
       d_pval_s = ar.take<int32_t>(P + 1);
       d_bidx = ar.take<uint32_t>(static_cast<size_t>(nbuckets) + 2);
       d_bfast = ar.take<int2>(static_cast<size_t>(nbuckets) + 1);
+      d_bidx_all = bucket_shift_all != bucket_shift ? ar.take<uint32_t>(static_cast<size_t>(nbuckets_all) + 2) : nullptr;
+      d_bfast_all = bucket_shift_all != bucket_shift ? ar.take<int2>(static_cast<size_t>(nbuckets_all) + 1) : nullptr;
       if (pass == 0) ar.commit();
     }
     ar.arm(st);
@@ -754,6 +765,15 @@ struct LinearPath {
                        d_bfast);
     WP_LAUNCH_CHECK();
     steps = StepTable{pstart, d_pval_p, d_pval_s, d_bidx, bucket_shift, pack_steps, d_bfast};
+    steps_all = steps;
+    if (bucket_shift_all != bucket_shift) {
+      hipLaunchKernelGGL(piece_bucket_kernel, dim3(cdiv(nbuckets_all + 1, kBlock)), dim3(kBlock), 0, st, pstart, P, bucket_shift_all,
+                         nbuckets_all, d_bidx_all);
+      hipLaunchKernelGGL(piece_bucket_fast_kernel, dim3(cdiv(nbuckets_all, kBlock)), dim3(kBlock), 0, st, d_bidx_all, d_pval_p, d_pval_s,
+                         nbuckets_all, d_bfast_all);
+      WP_LAUNCH_CHECK();
+      steps_all = StepTable{pstart, d_pval_p, d_pval_s, d_bidx_all, bucket_shift_all, pack_steps, d_bfast_all};
+    }
   }
 
   // words longer than a lane should walk (walk.h, "long words"): pointer doubling instead.  Scratch: the slabs of the sort.
@@ -787,7 +807,9 @@ struct LinearPath {
     uint32_t *jump_a = X1, *jump_b = reinterpret_cast<uint32_t *>(KA);
     uint8_t *d_mark = reinterpret_cast<uint8_t *>(KB);
     const dim3 grid(cdiv(total, kBlock));
-    hipLaunchKernelGGL(long_word_next_kernel, grid, dim3(kBlock), 0, st, wa, d_lw, d_lw_off, nw, total, d_lid, jump_a, d_mark);
+    WalkArgs wa_all = wa;  // (every position of the long words is looked up: the small index)
+    wa_all.steps = steps_all;
+    hipLaunchKernelGGL(long_word_next_kernel, grid, dim3(kBlock), 0, st, wa_all, d_lw, d_lw_off, nw, total, d_lid, jump_a, d_mark);
     WP_HIP(hipStreamSynchronize(st));  // h_off is a stack-owned upload source
     for (uint32_t reach = 1; reach < longest; reach *= 2) {  // after r rounds: chain prefixes of length 2^r
       hipLaunchKernelGGL(long_word_mark_kernel, grid, dim3(kBlock), 0, st, jump_a, total, d_mark);
@@ -868,7 +890,9 @@ struct LinearPath {
         WP_HIP(hipMemsetAsync(c->d_scalars + 13, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(wide_collect_kernel, dim3(std::min<size_t>(cdiv(acap, kBlock), 2048)), dim3(kBlock), 0, st, d_anchors,
                            c->d_scalars + 10, n_text, d_wide_list, c->d_scalars + 13);
-        hipLaunchKernelGGL(walk_wide_kernel, dim3(std::min<size_t>(cdiv(acap, kBlock / kWave), 8192)), dim3(kBlock), 0, st, wa, d_anchors,
+        WalkArgs wa_all = wa;  // (every position of the wide words is looked up: the small index)
+        wa_all.steps = steps_all;
+        hipLaunchKernelGGL(walk_wide_kernel, dim3(std::min<size_t>(cdiv(acap, kBlock / kWave), 8192)), dim3(kBlock), 0, st, wa_all, d_anchors,
                            c->d_scalars + 10, d_wide_list, c->d_scalars + 13, d_wide_cnt);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(walk_lean_kernel<true>), dim3(sblocks), dim3(kBlock), 0, st, wa, d_anchors,
                            c->d_scalars + 10, acap, d_ctmp, d_blk_cnt, d_wide_cnt);

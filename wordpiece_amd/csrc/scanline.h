@@ -29,7 +29,11 @@ constexpr uint32_t kMarkLenMask = 0x0fffffffu;
 #ifndef WP_STEP_BUCKET_BITS
 #define WP_STEP_BUCKET_BITS 18
 #endif
-constexpr int kStepBucketBits = WP_STEP_BUCKET_BITS;  // the step table's index: at most 2^bits buckets of SA slots
+constexpr int kStepBucketBits = WP_STEP_BUCKET_BITS;  // the step table's index: 2^18 .. 2^21 buckets of SA slots (linear_path.h)
+#ifndef WP_STEP_BUCKET_BITS_MAX
+#define WP_STEP_BUCKET_BITS_MAX 21
+#endif
+constexpr int kStepBucketBitsMax = WP_STEP_BUCKET_BITS_MAX;
 constexpr int kStepIdBits = 20;
 constexpr int kStepMaxLen = 1 << 11;
 constexpr uint32_t kMarkSurvBwd = 1u << 28;  // on the stack when the right->left scan leaves the tile

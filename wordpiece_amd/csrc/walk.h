@@ -783,11 +783,13 @@ __global__ __launch_bounds__(kBlock) void walk_wide_kernel(WalkArgs a, const uin
 }
 
 // the lists of a workgroup's words, one behind the other, at ctmp[position of its first anchor ...]: thread t
-// appends words kPer * t ... (cnt[w]: ids of word w, | kWideFlag: all of them in the word's own stretch of emit)
+// appends words kPer * t ... (cnt[w]: ids of word w, | kWideFlag: all of them in the word's own stretch of emit — those
+// are copied by whole waves afterwards, coalesced: a wide word has hundreds of ids, woff keeps where they go)
 template <int WORDS, bool WIDE>
 __device__ __forceinline__ void assemble_word_lists(const int32_t *__restrict__ emit, const uint32_t *__restrict__ anchors, size_t a0,
                                                     size_t na, const int32_t *stage, const uint32_t *cnt, uint32_t *sm,
-                                                    int32_t *__restrict__ ctmp, uint32_t *__restrict__ blk_cnt) {
+                                                    int32_t *__restrict__ ctmp, uint32_t *__restrict__ blk_cnt,
+                                                    uint32_t *woff, const uint32_t *wstart) {
   constexpr int kPer = WORDS / kBlock;
   uint32_t mine = 0;
 #pragma unroll
@@ -799,13 +801,56 @@ __device__ __forceinline__ void assemble_word_lists(const int32_t *__restrict__ 
   for (int q = 0; q < kPer; q++) {
     const int wq = threadIdx.x * kPer + q;
     const uint32_t c = cnt[wq] & (WIDE ? ~kWideFlag : ~0u);
-    const uint32_t staged = (WIDE && (cnt[wq] & kWideFlag)) ? 0u : static_cast<uint32_t>(kStageIds);  // (a wide word: everything in its stretch)
+    if (WIDE) woff[wq] = ex;
     if (c == 0) continue;
-    const int32_t *spill = c > staged ? emit + anchors[a0 + wq] : nullptr;
-    for (uint32_t j = 0; j < c; j++) {
-      ctmp[base + ex + j] = j < staged ? stage[j * WORDS + wq] : spill[j];
+    if (!(WIDE && (cnt[wq] & kWideFlag))) {
+      const int32_t *spill = c > static_cast<uint32_t>(kStageIds) ? emit + anchors[a0 + wq] : nullptr;
+      for (uint32_t j = 0; j < c; j++) {
+        ctmp[base + ex + j] = j < static_cast<uint32_t>(kStageIds) ? stage[j * WORDS + wq] : spill[j];
+      }
     }
     ex += c;
+  }
+  if (WIDE) {
+    __syncthreads();
+    // two words per trip, all loads (<= 256 ids per word and trip) before the stores: a wave has 8 loads in flight
+    // instead of one, and word starts come from LDS (wstart, filled when the word was dealt) — a copy loop with one
+    // load per trip behind a global load of the word's start made this kernel slower than the thread-serial copy
+    const int lane = lane_id();
+    constexpr int kW = 2, kC = 4, kStride = kBlock / kWave;
+    for (int w0 = wave_id(); w0 < WORDS; w0 += kW * kStride) {
+      uint32_t c[kW], done = 0;
+      const int32_t *src[kW];
+      int32_t *dst[kW];
+#pragma unroll
+      for (int u = 0; u < kW; u++) {
+        const int wq = w0 + u * kStride;
+        const uint32_t cw = wq < WORDS ? cnt[wq] : 0u;  // (wave-uniform)
+        c[u] = (cw & kWideFlag) ? (cw & ~kWideFlag) : 0u;
+        src[u] = emit + (wq < WORDS ? wstart[wq] : 0u);
+        dst[u] = ctmp + base + (wq < WORDS ? woff[wq] : 0u);
+      }
+      while (done < max(c[0], c[1])) {
+        int32_t v[kW][kC];
+#pragma unroll
+        for (int u = 0; u < kW; u++) {
+#pragma unroll
+          for (int q = 0; q < kC; q++) {
+            const uint32_t j = done + static_cast<uint32_t>(q) * kWave + lane;
+            v[u][q] = j < c[u] ? src[u][j] : 0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kW; u++) {
+#pragma unroll
+          for (int q = 0; q < kC; q++) {
+            const uint32_t j = done + static_cast<uint32_t>(q) * kWave + lane;
+            if (j < c[u]) dst[u][j] = v[u][q];
+          }
+        }
+        done += kC * kWave;
+      }
+    }
   }
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
 }
@@ -832,6 +877,7 @@ __global__ __launch_bounds__(kBlock) void walk_balanced_kernel(Args a, const uin
   // the word's own stretch of a.emit, their count (| kWideFlag) in wide_cnt[anchor index]
   __shared__ int32_t stage[kStageIds * kWbWords];
   __shared__ uint32_t cnt[kWbWords];
+  __shared__ uint32_t woff[WIDE ? kWbWords : 1], wstart[WIDE ? kWbWords : 1];  // (assemble_word_lists)
   __shared__ uint32_t sm[8];
   const int lane = lane_id(), w = wave_id();
   const size_t na = min(cap, static_cast<size_t>(*n_anchors_dev));
@@ -850,6 +896,7 @@ __global__ __launch_bounds__(kBlock) void walk_balanced_kernel(Args a, const uin
     const uint32_t hi = k + 1 < static_cast<size_t>(*n_anchors_dev) ? anchors[k + 1] : static_cast<uint32_t>(a.n_text);
     if (hi - start <= kWideMin) return false;
     cnt[wd] = wide_cnt[k];
+    wstart[wd] = start;
     return true;
   };
   if (active) {
@@ -884,7 +931,7 @@ __global__ __launch_bounds__(kBlock) void walk_balanced_kernel(Args a, const uin
     if (!__ballot(active) && (!WIDE || next >= kWbPerWave)) break;
   }
   __syncthreads();
-  assemble_word_lists<kWbWords, WIDE>(a.emit, anchors, a0, na, stage, cnt, sm, ctmp, blk_cnt);
+  assemble_word_lists<kWbWords, WIDE>(a.emit, anchors, a0, na, stage, cnt, sm, ctmp, blk_cnt, woff, wstart);
 }
 
 // The Linear walk, lean.  The kernel above is generic (Fast and Linear steps) and its Linear step is instruction bound,
@@ -902,6 +949,7 @@ __global__ __launch_bounds__(kBlock) void walk_lean_kernel(WalkArgs a, const uin
                                                            const uint32_t *__restrict__ wide_cnt) {
   __shared__ int32_t stage[kStageIds * kWbWords];
   __shared__ uint32_t cnt[kWbWords];
+  __shared__ uint32_t woff[WIDE ? kWbWords : 1], wstart[WIDE ? kWbWords : 1];  // (assemble_word_lists)
   __shared__ uint32_t sm[8];
   const int lane = lane_id(), w = wave_id();
   const size_t na = min(cap, static_cast<size_t>(*n_anchors_dev));
@@ -928,6 +976,7 @@ __global__ __launch_bounds__(kBlock) void walk_lean_kernel(WalkArgs a, const uin
       const uint32_t hi = k + 1 < static_cast<size_t>(*n_anchors_dev) ? anchors[k + 1] : end;
       if (hi - start > kWideMin) {
         cnt[wd] = wide_cnt[k];
+        wstart[wd] = start;
         return false;
       }
     }
@@ -1015,7 +1064,7 @@ __global__ __launch_bounds__(kBlock) void walk_lean_kernel(WalkArgs a, const uin
     if (!__ballot(active) && next >= mine) break;
   }
   __syncthreads();
-  assemble_word_lists<kWbWords, WIDE>(a.emit, anchors, a0, na, stage, cnt, sm, ctmp, blk_cnt);
+  assemble_word_lists<kWbWords, WIDE>(a.emit, anchors, a0, na, stage, cnt, sm, ctmp, blk_cnt, woff, wstart);
 }
 
 // ids[blk_off[b] ...] = the list of workgroup b (of the walk kernel, which took `words` anchors per workgroup)
