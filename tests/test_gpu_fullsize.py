@@ -76,6 +76,8 @@ def _check_config(kind, nbytes, vocab_size, window, expect_vocab_in_s=0, fast_mu
 def test_config4_one_shard_1250mb():
     st = _check_config("english", 1.25e9, 29000, 48_000_000)
     assert st["rounds"] <= 4 and st["n_total"] == st["n_text"] + 1
+    # HBM held by the handle's arenas (reserved for this text, then used): at most 60 bytes per symbol (105 in round 2)
+    assert st["arena_bytes"] <= 60 * st["n_total"], st["arena_bytes"] / st["n_total"]
 
 
 def test_config3_multilingual_1gb():

@@ -39,12 +39,13 @@ struct EnvOptions {
 struct DeviceBuffer {
   void *p = nullptr;
   size_t cap = 0;
-  void ensure(size_t bytes) {
+  // slack: room for a somewhat larger next text without another hipFree / hipMalloc
+  void ensure(size_t bytes, bool slack = true) {
     if (bytes <= cap) return;
     if (p) WP_HIP(hipFree(p));
     p = nullptr;
     cap = 0;
-    size_t want = bytes + bytes / 8 + (1 << 20);
+    size_t want = slack ? bytes + bytes / 16 + (1 << 20) : bytes;
     WP_HIP(hipMalloc(&p, want));
     cap = want;
   }

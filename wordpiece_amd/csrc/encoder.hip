@@ -500,12 +500,14 @@ int wp_linear_encode(wp_vocab *v, const char *utf8, size_t nbytes, int32_t **ids
 int wp_reserve(wp_vocab *v, size_t nbytes) {
   return guarded([&] {
     Context *c = get_context(v);
-    // arenas as an encode of `nbytes` of text would size them (about 100 bytes per symbol, DESIGN.md section 3;
-    // an estimate: an encode that needs more grows them as before)
+    // arenas as an encode of `nbytes` of ASCII text would size them in the default layout (43
+    // bytes per symbol + the refinement list for an eighth of the text; an estimate — an encode that needs more,
+    // a larger alphabet or the reference layout, grows them as before)
     const size_t n = nbytes + 1 + v->hv.stream.size();
-    c->text_buf.ensure(nbytes + 64);
-    c->a_buf.ensure(nbytes + nbytes / 512 + (size_t(1) << 20) + (v->keep_debug ? 4 * nbytes : 0));
-    c->b_buf.ensure(108 * n + (v->keep_debug ? 4 * n : 0) + (size_t(64) << 20));
+    const size_t per_symbol = (v->keep_debug || v->vocab_in_s || v->full_depth) ? 108 : 56;
+    c->text_buf.ensure(nbytes + 64, false);
+    c->a_buf.ensure(nbytes + nbytes / 512 + (size_t(1) << 20) + (v->keep_debug ? 4 * nbytes : 0), false);
+    c->b_buf.ensure(per_symbol * n + (v->keep_debug ? 4 * n : 0) + (size_t(64) << 20), false);
     PinnedBlock warm(nbytes + (size_t(1) << 20));  // about a quarter of an id per byte, 4 bytes each
   });
 }

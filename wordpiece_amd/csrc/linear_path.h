@@ -837,12 +837,11 @@ struct LinearPath {
                        v->cover_anchors ? 1 : 0, d_gap_a, d_gap_b);
     hipLaunchKernelGGL(reach_kernel, dim3(rtiles), dim3(kBlock), 0, st, wa, d_reach, d_reach_tiles, d_gap_a, d_gap_b);
     hipLaunchKernelGGL(reach_spine_kernel, dim3(1), dim3(1024), 0, st, d_reach_tiles, static_cast<size_t>(rtiles));
+    WP_HIP(hipMemsetAsync(d_anchor_cnt, 0, sizeof(uint32_t) * atiles, st));
     hipLaunchKernelGGL(cover_flags_kernel, dim3(rtiles), dim3(kBlock), 0, st, d_cls, d_reach, d_reach_tiles, n_text, d_aflags,
-                       d_wp_tiles, d_ns_tiles, d_gap_a, d_gap_b);
-    hipLaunchKernelGGL(suffix_min_kernel, dim3(1), dim3(1024), 0, st, d_wp_tiles, static_cast<size_t>(rtiles));
-    hipLaunchKernelGGL(suffix_min_kernel, dim3(1), dim3(1024), 0, st, d_ns_tiles, static_cast<size_t>(rtiles));
-    hipLaunchKernelGGL(anchor_count_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, d_aflags, n_text, d_anchor_cnt);
-    device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st);
+                       d_wp_tiles, d_ns_tiles, d_gap_a, d_gap_b, d_anchor_cnt);
+    hipLaunchKernelGGL(suffix_min_kernel, dim3(2), dim3(1024), 0, st, d_wp_tiles, d_ns_tiles, static_cast<size_t>(rtiles));
+    device_exclusive_scan(d_anchor_cnt, d_anchor_cnt, atiles, d_anchor_tmp, c->d_scalars + 10, st);  // (counted by cover_flags_kernel)
     hipLaunchKernelGGL(anchor_write_kernel, dim3(atiles), dim3(kBlock), 0, st, d_cls, d_aflags, n_text, d_anchor_cnt, d_anchors);
     WP_LAUNCH_CHECK();
     fetch_scalars(c, 11);

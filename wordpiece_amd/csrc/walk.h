@@ -423,24 +423,34 @@ __global__ __launch_bounds__(kBlock) void reach_kernel(WalkArgs a, uint32_t *__r
 
 // in place: tile_max[t] <- max over tiles before t (single workgroup)
 __global__ __launch_bounds__(1024) void reach_spine_kernel(uint32_t *__restrict__ tile_max, size_t tiles) {
-  __shared__ int32_t wm[16];
+  __shared__ int32_t wm[2][16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int kTrip = 4;  // (steps per trip, their loads issued together: suffix_min_kernel)
   int32_t carry = 0;
-  for (size_t base = 0; base < tiles; base += 1024) {
-    const size_t i = base + threadIdx.x;
-    const int32_t v = i < tiles ? static_cast<int32_t>(tile_max[i]) : 0;
-    const int32_t inc = wave_incl_max(v);
-    if (lane == kWave - 1) wm[w] = inc;
-    __syncthreads();
-    int32_t before = carry, all = carry;
-    for (int q = 0; q < 16; q++) {
-      if (q < w) before = max(before, wm[q]);
-      all = max(all, wm[q]);
+  int buf = 0;
+  for (size_t base = 0; base < tiles; base += 1024 * kTrip) {
+    int32_t v[kTrip];
+#pragma unroll
+    for (int k = 0; k < kTrip; k++) {
+      const size_t i = base + static_cast<size_t>(k) * 1024 + threadIdx.x;
+      v[k] = i < tiles ? static_cast<int32_t>(tile_max[i]) : 0;
     }
-    const int32_t up = __shfl_up(inc, 1, kWave);
-    if (i < tiles) tile_max[i] = static_cast<uint32_t>(lane == 0 ? before : max(before, up));
-    carry = all;
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kTrip; k++) {
+      const size_t i = base + static_cast<size_t>(k) * 1024 + threadIdx.x;
+      const int32_t inc = wave_incl_max(v[k]);
+      if (lane == kWave - 1) wm[buf][w] = inc;
+      __syncthreads();  // (two buffers taking turns)
+      int32_t before = carry, all = carry;
+      for (int q = 0; q < 16; q++) {
+        if (q < w) before = max(before, wm[buf][q]);
+        all = max(all, wm[buf][q]);
+      }
+      const int32_t up = __shfl_up(inc, 1, kWave);
+      if (i < tiles) tile_max[i] = static_cast<uint32_t>(lane == 0 ? before : max(before, up));
+      carry = all;
+      buf ^= 1;
+    }
   }
 }
 
@@ -453,9 +463,14 @@ __global__ __launch_bounds__(kBlock) void cover_flags_kernel(const uint8_t *__re
                                                              uint32_t *__restrict__ tile_first_wp,
                                                              uint32_t *__restrict__ tile_first_ns,
                                                              const uint32_t *__restrict__ gap_a_end,
-                                                             const uint32_t *__restrict__ gap_b_start) {
+                                                             const uint32_t *__restrict__ gap_b_start,
+                                                             uint32_t *__restrict__ anchor_cnt) {
+  // anchor_cnt (cleared by the caller): the flags set per tile of kAnchorTile positions — what anchor_count_kernel
+  // would count in a pass of its own
+  static_assert(kAnchorTile % kReachTile == 0, "a tile of this kernel lies inside one tile of the anchor list");
   __shared__ int32_t wm[4];
   __shared__ int32_t sm_min[8];
+  uint32_t set = 0;
   int32_t first_wp = 0x7fffffff, first_ns = 0x7fffffff;  // first word-prefix / non-space position of this thread
   const int lane = lane_id(), w = wave_id();
   const size_t p0 = static_cast<size_t>(blockIdx.x) * kReachTile + static_cast<size_t>(threadIdx.x) * 8;
@@ -484,7 +499,9 @@ __global__ __launch_bounds__(kBlock) void cover_flags_kernel(const uint8_t *__re
       const bool wp = p == 0 || (c & kClsSpacing) || (cp & kClsSpacing);
       const bool covered_rule = p < ga || p >= gb;
       const bool anchor = covered_rule ? (wp && cover <= static_cast<int32_t>(p)) : (p == 0 || w_hard(c) || w_hard(cp));
-      aflags[p] = (!(c & kClsSpace) && anchor) ? 1 : 0;
+      const bool flag = !(c & kClsSpace) && anchor;
+      aflags[p] = flag ? 1 : 0;
+      set += flag ? 1u : 0u;
       cover = max(cover, r[j]);
       if (wp) first_wp = min(first_wp, static_cast<int32_t>(p));
       if (!(c & kClsSpace)) first_ns = min(first_ns, static_cast<int32_t>(p));
@@ -492,38 +509,57 @@ __global__ __launch_bounds__(kBlock) void cover_flags_kernel(const uint8_t *__re
   }
   const int32_t m = block_reduce_min(first_wp, sm_min);
   const int32_t m2 = block_reduce_min(first_ns, sm_min);
+  uint32_t nset = 0;
+  (void)block_excl_sum(set, reinterpret_cast<uint32_t *>(sm_min), nset);  // (starts with a barrier of its own)
   if (threadIdx.x == 0) {
+    if (anchor_cnt && nset) atomicAdd(&anchor_cnt[blockIdx.x / (kAnchorTile / kReachTile)], nset);
     tile_first_wp[blockIdx.x] = m == 0x7fffffff ? static_cast<uint32_t>(n) : static_cast<uint32_t>(m);
     tile_first_ns[blockIdx.x] = m2 == 0x7fffffff ? static_cast<uint32_t>(n) : static_cast<uint32_t>(m2);
   }
 }
 
-// in place: t[i] <- min over tiles >= i (single workgroup, from the back)
-__global__ __launch_bounds__(1024) void suffix_min_kernel(uint32_t *__restrict__ t, size_t tiles) {
-  __shared__ uint32_t wm[16];
+// in place: t[i] <- min over tiles >= i (one workgroup per array, from the back).  Four steps of 1024 tiles per trip:
+// their loads are issued together (the loop is a chain of load -> scan -> store, one memory latency per step
+// otherwise: 0.28 ms for the 270 K tiles of config 3).
+__global__ __launch_bounds__(1024) void suffix_min_kernel(uint32_t *__restrict__ t0, uint32_t *__restrict__ t1, size_t tiles) {
+  uint32_t *__restrict__ t = blockIdx.x == 0 ? t0 : t1;
+  __shared__ uint32_t wm[2][16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int kTrip = 4;
   uint32_t carry = 0xffffffffu;
-  for (size_t done = 0; done < tiles; done += 1024) {
-    // this step covers indices [hi - 1024, hi) from the back; thread x owns index hi - 1 - x
-    const size_t hi = tiles - done;
-    const bool ok = threadIdx.x < hi;
-    const size_t i = ok ? hi - 1 - threadIdx.x : 0;
-    uint32_t v = ok ? t[i] : 0xffffffffu;
+  int buf = 0;
+  for (size_t done = 0; done < tiles; done += 1024 * kTrip) {
+    uint32_t v[kTrip];
+    size_t idx[kTrip];
+    bool ok[kTrip];
 #pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const uint32_t u = __shfl_up(v, d, kWave);
-      if (lane >= d) v = min(v, u);
+    for (int k = 0; k < kTrip; k++) {
+      // step k covers indices [hi - 1024, hi) from the back; thread x owns index hi - 1 - x
+      const size_t off = done + static_cast<size_t>(k) * 1024;
+      const size_t hi = off < tiles ? tiles - off : 0;
+      ok[k] = threadIdx.x < hi;
+      idx[k] = ok[k] ? hi - 1 - threadIdx.x : 0;
+      v[k] = ok[k] ? t[idx[k]] : 0xffffffffu;
     }
-    if (lane == kWave - 1) wm[w] = v;
-    __syncthreads();
-    uint32_t before = carry, all = carry;
-    for (int q = 0; q < 16; q++) {
-      if (q < w) before = min(before, wm[q]);
-      all = min(all, wm[q]);
+#pragma unroll
+    for (int k = 0; k < kTrip; k++) {
+      uint32_t x = v[k];
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t u = __shfl_up(x, d, kWave);
+        if (lane >= d) x = min(x, u);
+      }
+      if (lane == kWave - 1) wm[buf][w] = x;
+      __syncthreads();  // (two buffers taking turns: the next step's writes cannot meet this step's reads)
+      uint32_t before = carry, all = carry;
+      for (int q = 0; q < 16; q++) {
+        if (q < w) before = min(before, wm[buf][q]);
+        all = min(all, wm[buf][q]);
+      }
+      if (ok[k]) t[idx[k]] = min(x, before);
+      carry = all;
+      buf ^= 1;
     }
-    if (ok) t[i] = min(v, before);
-    carry = all;
-    __syncthreads();
   }
 }
 
