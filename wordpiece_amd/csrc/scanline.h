@@ -282,13 +282,24 @@ __global__ __launch_bounds__(kCoverThreads) void mark_cover_kernel(const uint32_
   for (int base = 0; base < M; base += kCoverThreads * kCoverItems) {
     // forward: running max of reach_fwd; backward: running min of reach_bwd as a max of negated values,
     // taken over the marks in reverse order (scan index i <-> mark M-1-i)
+    // (all loads of a step issued before the first use, none behind a branch: eight marks per thread were eight
+    // chains of info -> reach in a row, 62 us for 29 k marks)
     int32_t v[kCoverItems], mx = kNone;
+    uint32_t info[kCoverItems];
+    int32_t rv[kCoverItems];
+    const int32_t *__restrict__ reach = back ? reach_bwd : reach_fwd;
 #pragma unroll
     for (int j = 0; j < kCoverItems; j++) {
       const int i = base + tid * kCoverItems + j;
-      const int q = back ? M - 1 - i : i;
+      const int q = i < M ? (back ? M - 1 - i : i) : 0;
+      info[j] = minfo[q];
+      rv[j] = reach[q];
+    }
+#pragma unroll
+    for (int j = 0; j < kCoverItems; j++) {
+      const int i = base + tid * kCoverItems + j;
       v[j] = kNone;
-      if (i < M && static_cast<int>(minfo[q] >> kMarkClsShift) == c) v[j] = back ? -reach_bwd[q] - 1 : reach_fwd[q];
+      if (i < M && static_cast<int>(info[j] >> kMarkClsShift) == c) v[j] = back ? -rv[j] - 1 : rv[j];
       mx = max(mx, v[j]);
       v[j] = mx;  // inclusive within the thread
     }
