@@ -347,15 +347,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
       rnk[r] = wave_rank_digit<kRadixBits>(mycnt, d, lane);
     } else {
       // (out-of-range slots of the last tile share the top bin with real keys here: they must still rank behind
-      // them, so they are counted after the loop).  A round in which many lanes hold one digit — the destination
-      // digits of a text whose sorted order runs along the text, config 5 — would serialise on that counter: such a
-      // round is ranked by match-any instead (both forms leave the counter at the number of keys ranked so far).
-      const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-      if (__popcll(__ballot(d == d0)) > 16 && wave_base + static_cast<size_t>(r + 1) * kWave <= n) {  // (wave-uniform)
-        rnk[r] = wave_rank_digit<kRadixBits>(mycnt, d, lane);
-      } else {
-        rnk[r] = i < n ? atomicAdd(&wcnt[w][d], 1u) : 0u;
-      }
+      // them, so they are counted after the loop)
+      rnk[r] = i < n ? atomicAdd(&wcnt[w][d], 1u) : 0u;
     }
   }
   if (!STABLE && wave_base + static_cast<size_t>(ITEMS) * kWave > n) {  // (wave-uniform: the wave that holds the end)
