@@ -1024,17 +1024,9 @@ __global__ __launch_bounds__(kBlock) void walk_lean_kernel(WalkArgs a, const uin
     if (active) {
       bool done = true;
       if (p < end) {
-#ifdef WP_AB_NT
-        // (streams pass through the L2 once: marked non-temporal so that they do not push the step table out of it)
-        const uint32_t r = rank_of(__builtin_nontemporal_load(a.rank + p));
-        typedef uint32_t cls16 __attribute__((ext_vector_type(4), aligned(1)));
-        const cls16 cv = __builtin_nontemporal_load(reinterpret_cast<const cls16 *>(a.cls + p));
-        const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
-#else
         const uint32_t r = rank_of(a.rank[p]);
         uint32_t cw[4];  // class bytes of p .. p + 15 (the array has 16 bytes of slack behind the text)
         __builtin_memcpy(cw, a.cls + p, 16);
-#endif
         const int32_t raw = step_raw(a.steps, r, (cw[0] & kClsWordPrefix) != 0);
         const int32_t id = step_id(a.steps, raw);
         bool fast = id >= 0 && wp_in_bounds(id < a.n_tokens, kSiteTokenId);
