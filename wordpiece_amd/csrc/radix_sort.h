@@ -291,7 +291,9 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned ntiles) {
 // order — so a key takes its rank inside the wave from ONE LDS atomic on the wave's digit counter (the old value)
 // instead of the 8-ballot match-any (about 40 VALU instructions per key; DESIGN.md: the ranking is half of a pass).
 // vin == nullptr: the values are the element indices (the identity), made up here instead of read.
-template <typename KeyT, int ITEMS, bool STABLE = true>
+// RBITS: bits of the digit that can be set (the ranking takes one ballot per bit: a 6-bit digit — the second
+// destination-partition pass of the rank store — ranks with 6 ballots instead of 8).
+template <typename KeyT, int ITEMS, bool STABLE = true, int RBITS = kRadixBits>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
     uint32_t *__restrict__ vout, size_t n, int begin_bit, uint32_t mask,
@@ -302,6 +304,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
   // value (the sort that follows is keyed by the values: the destination partition of the rank store).
   constexpr int TILE = kBlock * ITEMS;
   constexpr int WAVES = kBlock / kWave;
+  constexpr uint32_t kOob = (1u << RBITS) - 1u;  // bin of the slots past the end: the last one that can hold keys
+  static_assert(STABLE || RBITS == kRadixBits, "the first-pass form counts the slots past the end in the top bin");
   __shared__ uint32_t wcnt[WAVES][kRadixBins];
   __shared__ uint32_t dstart[kRadixBins];
   __shared__ uint32_t gbase[kRadixBins];
@@ -342,9 +346,9 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
     size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
     // out-of-range slots (only at the very end of the last tile) take the top bin: they are the
     // last keys in tile order, hence rank after every valid key and are never written back
-    const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : (kRadixBins - 1);
+    const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : kOob;
     if (STABLE) {
-      rnk[r] = wave_rank_digit<kRadixBits>(mycnt, d, lane);
+      rnk[r] = wave_rank_digit<RBITS>(mycnt, d, lane);
     } else {
       // (out-of-range slots of the last tile share the top bin with real keys here: they must still rank behind
       // them, so they are counted after the loop)
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
     size_t i = wave_base + static_cast<size_t>(r) * kWave + lane;
-    const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : (kRadixBins - 1);
+    const uint32_t d = i < n ? (static_cast<uint32_t>(key[r] >> begin_bit) & mask) : kOob;
     const uint32_t pos = dstart[d] + wcnt[w][d] + rnk[r];
     skeys[pos] = key[r];
     svals[pos] = val[r];
@@ -589,6 +593,9 @@ int radix_sort_ranges(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, size_t n, 
                          dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
     } else if (pi == 0 && input_order_free) {  // (no earlier order to keep: ranks by LDS atomics)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, false>), dim3(ntiles),
+                         dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
+    } else if (sizeof(KeyT) == 4 && mask < 64u) {  // (a digit of at most 6 bits)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, true, 6>), dim3(ntiles),
                          dim3(kBlock), 0, st, ki, vsrc, ko, vo, n, b, mask, table, dgo, nbit, nmask, from_val);
     } else {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_scatter_kernel<KeyT, RadixCfg<KeyT>::kItems, true>), dim3(ntiles),
