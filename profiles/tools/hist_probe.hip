@@ -24,7 +24,7 @@ int main() {
       WP_HIP(hipMemsetAsync(tmp, 0, radix_tmp_words<uint64_t>(n) * 4, 0));
       WP_HIP(hipEventRecord(e0));
       hipLaunchKernelGGL(HIP_KERNEL_NAME(radix_hist_kernel<uint64_t, RadixCfg<uint64_t>::kItems>), dim3(ntiles), dim3(kBlock), 0, 0, k0,
-                         static_cast<const uint8_t *>(nullptr), n, bit, 255u, tmp, tmp + (size_t)ntiles * kRadixBins, 0, ntiles);
+                         static_cast<const uint8_t *>(nullptr), n, bit, 255u, tmp, tmp + (size_t)ntiles * kRadixBins, 0);
       WP_HIP(hipEventRecord(e1)); WP_HIP(hipEventSynchronize(e1));
       float ms; WP_HIP(hipEventElapsedTime(&ms, e0, e1));
       if (it > 0 && ms < best) best = ms;
