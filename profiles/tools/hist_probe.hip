@@ -38,7 +38,7 @@ int main() {
   st.spans.on = true;
   for (int it = 0; it < 3; it++) {
     WP_HIP(hipEventRecord(e0));
-    radix_sort_pairs<uint64_t>(k0, v0, k1, v1, n, 0, 16, tmp, 0, &st);
+    radix_sort_pairs<uint64_t>(k0, v0, k1, v1, n, 0, 16, tmp, radix_tmp_words<uint64_t>(n), 0, &st);
     WP_HIP(hipEventRecord(e1)); WP_HIP(hipEventSynchronize(e1));
     float ms; WP_HIP(hipEventElapsedTime(&ms, e0, e1));
     printf("2 passes: %.3f ms total, scatter spans %.3f ms\n", ms, st.spans.resolve());
